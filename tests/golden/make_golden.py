@@ -1,0 +1,502 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference; it never travels to the
+GPU box).  Every fixture stores explicit inputs, the full initial state_dict
+(including SN u/v and BN buffers), outputs, selected gradients and the
+post-forward state, so nothing depends on cross-version RNG streams.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixture ids follow SURVEY.md section 8(c): F1..F10.
+Key scheme inside each .npz:   in.<name>  sd0.<state_dict key>  out.<name>
+                               grad.<param key>  sd1.<state_dict key>  meta.<name>
+"""
+import os
+import sys
+import types
+import argparse
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def import_reference():
+    """Stub the two imports the image lacks, then import the reference modules."""
+    if "tensorboardX" not in sys.modules:
+        tb = types.ModuleType("tensorboardX")
+        tb.SummaryWriter = type("SummaryWriter", (), {})
+        sys.modules["tensorboardX"] = tb
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvu = types.ModuleType("torchvision.utils")
+        tvu.save_image = lambda *a, **k: None
+        tvu.make_grid = lambda x, *a, **k: x
+        tv.utils = tvu
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.utils"] = tvu
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    warnings.filterwarnings("ignore")
+    import Module.Normalization as N
+    import Module.ConvGRU as CG
+    import Module.GResBlock as GR
+    import Module.Generator as GE
+    import Module.Discriminators as DI
+    import Module.Attention as AT
+    import utils as U
+    return types.SimpleNamespace(N=N, CG=CG, GR=GR, GE=GE, DI=DI, AT=AT, U=U)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def put_sd(store, tag, module):
+    for k, v in module.state_dict().items():
+        store[f"{tag}.{k}"] = npy(v)
+
+
+def put_state(store, tag, module):
+    """Only what a forward pass mutates: SN u/v and BN buffers."""
+    for k, v in module.state_dict().items():
+        if k.endswith(("weight_u", "weight_v", "running_mean", "running_var", "num_batches_tracked")):
+            store[f"{tag}.{k}"] = npy(v)
+
+
+def put_grads(store, module, only=None):
+    for k, p in module.named_parameters():
+        if p.grad is not None and (only is None or k in only):
+            store[f"grad.{k}"] = npy(p.grad)
+
+
+def save(name, store):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  ({len(store)} arrays)")
+
+
+# ----------------------------------------------------------------------------- F1
+def f1_spectral_norm(R):
+    """SpectralNorm on Conv2d / Conv3d / Linear(->1) / Embedding: u, v, sigma-normalised
+    weight after 1 and 3 forwards, gradient wrt weight_bar (Normalization.py:10-64)."""
+    torch.manual_seed(101)
+    import torch.nn as nn
+    st = {}
+    cases = {
+        "conv2d": (nn.Conv2d(4, 8, 3, padding=1), torch.randn(2, 4, 5, 5)),
+        "conv3d": (nn.Conv3d(3, 6, 3, padding=1), torch.randn(2, 3, 4, 5, 5)),
+        "linear": (nn.Linear(16, 1), torch.randn(5, 16)),
+        "embed": (nn.Embedding(7, 16), torch.tensor([0, 3, 6, 3])),
+    }
+    for name, (inner, x) in cases.items():
+        sn = R.N.SpectralNorm(inner)
+        put_sd(st, f"{name}.sd0", sn)
+        st[f"{name}.in.x"] = npy(x)
+        y = sn(x)
+        st[f"{name}.out.y1"] = npy(y)
+        st[f"{name}.out.w1"] = npy(sn.module.weight)
+        gy = torch.randn_like(y)
+        st[f"{name}.in.gy"] = npy(gy)
+        y.backward(gy)
+        for k, p in sn.named_parameters():
+            if p.grad is not None:
+                st[f"{name}.grad.{k}"] = npy(p.grad)
+        put_sd(st, f"{name}.sd1", sn)
+        sn(x)
+        y3 = sn(x)
+        st[f"{name}.out.y3"] = npy(y3)
+        put_sd(st, f"{name}.sd3", sn)
+    save("f1_spectral_norm", st)
+
+
+# ----------------------------------------------------------------------------- F2
+def f2_conditional_norm(R):
+    """ConditionalNorm train + eval (Normalization.py:66-88)."""
+    torch.manual_seed(102)
+    st = {}
+    cn = R.N.ConditionalNorm(6, 10)
+    x = torch.randn(5, 6, 4, 4, requires_grad=True)
+    c = torch.randn(5, 10, requires_grad=True)
+    put_sd(st, "sd0", cn)
+    st["in.x"], st["in.cond"] = npy(x), npy(c)
+    cn.train()
+    y = cn(x, c)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    st["in.gy"] = npy(gy)
+    st["out.y_train"] = npy(y)
+    st["grad.x"], st["grad.cond"] = npy(x.grad), npy(c.grad)
+    put_grads(st, cn)
+    put_sd(st, "sd1", cn)
+    cn.eval()
+    st["out.y_eval"] = npy(cn(x, c))
+    save("f2_conditional_norm", st)
+
+
+# ----------------------------------------------------------------------------- F3
+def f3_gresblock(R):
+    """GResBlock with upsample_factor 1 and 2, fwd + bwd (GResBlock.py:42-86)."""
+    torch.manual_seed(103)
+    st = {}
+    for tag, up, cin, cout in (("up1", 1, 8, 8), ("up2", 2, 8, 4)):
+        blk = R.GR.GResBlock(cin, cout, n_class=12, upsample_factor=up)
+        x = torch.randn(6, cin, 4, 4, requires_grad=True)
+        cond = torch.randn(6, 12, requires_grad=True)
+        put_sd(st, f"{tag}.sd0", blk)
+        st[f"{tag}.in.x"], st[f"{tag}.in.cond"] = npy(x), npy(cond)
+        y = blk(x, cond)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        st[f"{tag}.in.gy"], st[f"{tag}.out.y"] = npy(gy), npy(y)
+        st[f"{tag}.grad.x"], st[f"{tag}.grad.cond"] = npy(x.grad), npy(cond.grad)
+        for k, p in blk.named_parameters():
+            if p.grad is not None:
+                st[f"{tag}.grad.{k}"] = npy(p.grad)
+        put_sd(st, f"{tag}.sd1", blk)
+    save("f3_gresblock", st)
+
+
+# ----------------------------------------------------------------------------- F4
+def f4_convgru(R):
+    """ConvGRUCell and 3-layer ConvGRU over T=4, kernels (3,5,5) fwd + BPTT (ConvGRU.py:29-133)."""
+    torch.manual_seed(104)
+    st = {}
+    cell = R.CG.ConvGRUCell(8, 16, 5)
+    for p in cell.parameters():  # non-zero biases so the bias path is exercised
+        if p.dim() == 1:
+            p.data.normal_(0, 0.1)
+    x = torch.randn(3, 8, 6, 6, requires_grad=True)
+    h = torch.randn(3, 16, 6, 6, requires_grad=True)
+    put_sd(st, "cell.sd0", cell)
+    st["cell.in.x"], st["cell.in.h"] = npy(x), npy(h)
+    y0 = cell(x)           # prev_state None -> zeros (ConvGRU.py:31-44)
+    y = cell(x, h)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    st["cell.out.y_h0"], st["cell.out.y"], st["cell.in.gy"] = npy(y0), npy(y), npy(gy)
+    st["cell.grad.x"], st["cell.grad.h"] = npy(x.grad), npy(h.grad)
+    for k, p in cell.named_parameters():
+        st[f"cell.grad.{k}"] = npy(p.grad)
+
+    gru = R.CG.ConvGRU(8, hidden_sizes=[8, 16, 8], kernel_sizes=[3, 5, 5], n_layers=3)
+    for p in gru.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.1)
+    T = 4
+    xs = torch.randn(T, 2, 8, 6, 6, requires_grad=True)
+    put_sd(st, "gru.sd0", gru)
+    st["gru.in.xs"] = npy(xs)
+    hidden, outs = None, []
+    for t in range(T):
+        hidden = gru(xs[t], hidden)
+        outs.append(hidden[-1])
+    y = torch.stack(outs)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    st["gru.out.y"], st["gru.in.gy"], st["gru.grad.xs"] = npy(y), npy(gy), npy(xs.grad)
+    for li, hl in enumerate(hidden):
+        st[f"gru.out.h_last.{li}"] = npy(hl)
+    for k, p in gru.named_parameters():
+        st[f"gru.grad.{k}"] = npy(p.grad)
+    save("f4_convgru", st)
+
+
+# ----------------------------------------------------------------------------- F5
+def f5_attention(R):
+    """2-D SelfAttention of the discriminators, gamma != 0 (Discriminators.py:82-119);
+    plus the (defined, never invoked) 5-D SelfAttention / SeparableAttn (Attention.py)."""
+    torch.manual_seed(105)
+    st = {}
+    for tag, C, S in (("n16", 16, 4), ("n64", 8, 8)):
+        at = R.DI.SelfAttention(C)
+        at.gamma.data.fill_(0.7)
+        for p in (at.query_conv.bias, at.key_conv.bias, at.value_conv.bias):
+            p.data.normal_(0, 0.1)
+        x = torch.randn(3, C, S, S, requires_grad=True)
+        put_sd(st, f"{tag}.sd0", at)
+        st[f"{tag}.in.x"] = npy(x)
+        y = at(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        st[f"{tag}.out.y"], st[f"{tag}.in.gy"], st[f"{tag}.grad.x"] = npy(y), npy(gy), npy(x.grad)
+        for k, p in at.named_parameters():
+            st[f"{tag}.grad.{k}"] = npy(p.grad)
+    a3 = R.AT.SelfAttention(8)
+    a3.gamma.data.fill_(0.5)
+    x = torch.randn(2, 8, 4, 4, 4, requires_grad=True)
+    put_sd(st, "attn3d.sd0", a3)
+    st["attn3d.in.x"] = npy(x)
+    y = a3(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    st["attn3d.out.y"], st["attn3d.in.gy"], st["attn3d.grad.x"] = npy(y), npy(gy), npy(x.grad)
+    for k, p in a3.named_parameters():
+        st[f"attn3d.grad.{k}"] = npy(p.grad)
+    sp = R.AT.SeparableAttn(8)
+    for m in sp.modules():
+        if hasattr(m, "gamma"):
+            m.gamma.data.fill_(0.3)
+    x = torch.randn(2, 8, 4, 4, 4, requires_grad=True)
+    put_sd(st, "sep.sd0", sp)
+    st["sep.in.x"] = npy(x)
+    y = sp(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    st["sep.out.y"], st["sep.in.gy"], st["sep.grad.x"] = npy(y), npy(gy), npy(x.grad)
+    save("f5_attention", st)
+
+
+# ----------------------------------------------------------------------------- F6
+def f6_generator(R):
+    """Generator ch=2: (B=3,T=4: B does not divide T) and (B=2,T=4: divides) pin the
+    condition mis-ordering quirk (Generator.py:103-110); latent_dim 2 and 4.
+    Case a stores every gradient; case b stores the output and a few gradients."""
+    st = {}
+    few = ("conv.0.cells.0.update_gate.weight", "conv.4.conv0.module.weight_bar",
+           "conv.11.CBNorm2.embed.weight", "embedding.weight", "affine_transfrom.bias")
+    for tag, B, T, ld, seed, full in (("a", 3, 4, 2, 106, True), ("b", 2, 4, 4, 107, False)):
+        torch.manual_seed(seed)
+        G = R.GE.Generator(in_dim=12, latent_dim=ld, n_class=3, ch=2, n_frames=T)
+        for k, p in G.named_parameters():  # exercise the bias paths of the GRU gates
+            if "gate.bias" in k:
+                p.data.normal_(0, 0.05)
+        z = torch.randn(B, 12)
+        cls = torch.randint(0, 3, (B,))
+        put_sd(st, f"{tag}.sd0", G)
+        st[f"{tag}.in.z"], st[f"{tag}.in.cls"] = npy(z), npy(cls)
+        G.train()
+        y = G(z, cls)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        st[f"{tag}.out.y"], st[f"{tag}.in.gy"] = npy(y), npy(gy)
+        for k, p in G.named_parameters():
+            if p.grad is not None and (full or k in few):
+                st[f"{tag}.grad.{k}"] = npy(p.grad)
+        put_state(st, f"{tag}.sd1", G)
+        G.eval()
+        with torch.no_grad():
+            st[f"{tag}.out.y_eval"] = npy(G(z, cls))
+        put_state(st, f"{tag}.sd2", G)
+    save("f6_generator", st)
+
+
+# ----------------------------------------------------------------------------- F7
+def f7_discriminators(R):
+    """SpatialDiscriminator / TemporalDiscriminator chn=2 fwd + bwd at 64x64
+    (+ D_s at 32x32; D_t at 32x32 frames is an expected RuntimeError)."""
+    st = {}
+    torch.manual_seed(108)
+    Ds = R.DI.SpatialDiscriminator(chn=2, n_class=3)
+    Ds.attn.gamma.data.fill_(0.4)
+    x = (torch.rand(2, 3, 3, 64, 64) * 2 - 1).requires_grad_(True)   # [B,k,3,H,W]
+    cls = torch.tensor([2, 0])
+    put_sd(st, "ds.sd0", Ds)
+    st["ds.in.x"], st["ds.in.cls"] = npy(x), npy(cls)
+    y = Ds(x, cls)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    st["ds.out.y"], st["ds.in.gy"], st["ds.grad.x"] = npy(y), npy(gy), npy(x.grad)
+    for k, p in Ds.named_parameters():
+        if p.grad is not None:
+            st[f"ds.grad.{k}"] = npy(p.grad)
+    put_sd(st, "ds.sd1", Ds)
+    x32 = torch.rand(2, 2, 3, 32, 32) * 2 - 1
+    st["ds32.in.x"] = npy(x32)
+    with torch.no_grad():
+        st["ds32.out.y"] = npy(Ds(x32, cls))
+
+    torch.manual_seed(109)
+    Dt = R.DI.TemporalDiscriminator(chn=2, n_class=3)
+    Dt.self_attn.gamma.data.fill_(-0.6)
+    x = (torch.rand(2, 3, 8, 32, 32) * 2 - 1).requires_grad_(True)   # [B,3,T,H/2,W/2]
+    put_sd(st, "dt.sd0", Dt)
+    st["dt.in.x"], st["dt.in.cls"] = npy(x), npy(cls)
+    y = Dt(x, cls)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    st["dt.out.y"], st["dt.in.gy"], st["dt.grad.x"] = npy(y), npy(gy), npy(x.grad)
+    for k, p in Dt.named_parameters():
+        if p.grad is not None:
+            st[f"dt.grad.{k}"] = npy(p.grad)
+    put_sd(st, "dt.sd1", Dt)
+    try:
+        Dt(torch.rand(1, 3, 8, 16, 16), cls[:1])
+        st["dt16.meta.raises"] = np.array(0)
+    except RuntimeError:
+        st["dt16.meta.raises"] = np.array(1)
+    save("f7_discriminators", st)
+
+
+# ----------------------------------------------------------------------------- F8
+def f8_helpers(R):
+    """sample_k_frames with recorded frame ids, vid_downsample (utils.py:60-63,77-83)."""
+    torch.manual_seed(110)
+    st = {}
+    data = torch.randn(2, 6, 3, 8, 8)
+    st["in.data"] = npy(data)
+    rec = {}
+    orig = torch.randperm
+
+    def spy(n, *a, **k):
+        r = orig(n, *a, **k)
+        rec["perm"] = r.clone()
+        return r
+    torch.randperm = spy
+    try:
+        out = R.U.sample_k_frames(data, 6, 4)
+        st["in.perm"], st["out.sample_k4"] = npy(rec["perm"]), npy(out)
+        out = R.U.sample_k_frames(data, 6, 9)      # k > T -> every frame, sorted
+        st["in.perm_k9"], st["out.sample_k9"] = npy(rec["perm"]), npy(out)
+    finally:
+        torch.randperm = orig
+    st["out.down"] = npy(R.U.vid_downsample(data))
+    save("f8_helpers", st)
+
+
+# ----------------------------------------------------------------------------- F9 / F10
+def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr=5e-5,
+                grads_of=(), n_batches=None):
+    """Drive the unmodified reference Trainer.train() (trainer.py:189-307) on CPU and
+    record every RNG draw, the six loss terms per step, named gradients and parameter
+    checksums at each optimizer.step()."""
+    import trainer as TR
+    import torch.nn as nn
+    nn.Module.cuda = lambda self, *a, **kw: self          # trainer.py:349-351 call .cuda()
+    torch.manual_seed(seed)
+    cfg = argparse.Namespace(
+        model="dvd-gan", adv_loss=adv_loss, imsize=64, g_num=5, z_dim=z_dim, g_chn=ch, ds_chn=ch,
+        dt_chn=ch, n_frames=T, g_conv_dim=64, d_conv_dim=64, lr_schr="const", lambda_gp=10,
+        total_epoch=1 if n_batches is None else steps // n_batches, d_iters=1, g_iters=1, batch_size=B, num_workers=0, g_lr=lr, d_lr=lr,
+        lr_decay=0.9999, beta1=0.0, beta2=0.9, pretrained_model=None, n_class=n_class,
+        k_sample=k, dataset="ucf101", use_tensorboard=False, test_batch_size=1,
+        image_path="/tmp/x", log_path="/tmp/x", model_save_path="/tmp/x", sample_path="/tmp/x",
+        log_epoch=10 ** 6, sample_epoch=10 ** 6, model_save_epoch=10 ** 6, version="g",
+        gpus=[], parallel=False)
+    gen = torch.Generator().manual_seed(seed + 1)
+    loader = [((torch.rand(B, 3, T, 64, 64, generator=gen) * 2 - 1),
+               torch.randint(0, n_class, (B,), generator=gen))
+              for _ in range(steps if n_batches is None else n_batches)]
+    tr = TR.Trainer(loader, cfg)
+    st = {}
+    put_sd(st, "G.sd0", tr.G)
+    put_sd(st, "Ds.sd0", tr.D_s)
+    put_sd(st, "Dt.sd0", tr.D_t)
+    for i, (v, l) in enumerate(loader):
+        st[f"in.real.{i}"], st[f"in.labels.{i}"] = npy(v), npy(l)
+
+    draws = {"randperm": [], "randn": [], "randint": []}
+    o_perm, o_randn, o_randint = torch.randperm, torch.randn, torch.randint
+
+    def w_perm(*a, **kw):
+        r = o_perm(*a, **kw); draws["randperm"].append(npy(r)); return r
+
+    def w_randn(*a, **kw):
+        r = o_randn(*a, **kw); draws["randn"].append(npy(r)); return r
+
+    def w_randint(*a, **kw):
+        r = o_randint(*a, **kw); draws["randint"].append(npy(r)); return r
+    losses = []
+    o_calc = tr.calc_loss
+
+    def w_calc(x, flag):
+        r = o_calc(x, flag); losses.append(float(r)); return r
+    tr.calc_loss = w_calc
+    snaps = {"Ds": [], "Dt": [], "G": []}
+
+    def wrap_opt(opt, net, tag):
+        o_step = opt.step
+
+        def stepper(*a, **kw):
+            g = {kk: npy(p.grad) for kk, p in net.named_parameters()
+                 if p.grad is not None and kk in grads_of}
+            gsum = {kk: float(p.grad.double().abs().sum()) for kk, p in net.named_parameters()
+                    if p.grad is not None}
+            r = o_step(*a, **kw)
+            psum = {kk: float(v.double().abs().sum()) for kk, v in net.state_dict().items()}
+            snaps[tag].append((g, gsum, psum))
+            return r
+        opt.step = stepper
+    wrap_opt(tr.ds_optimizer, tr.D_s, "Ds")
+    wrap_opt(tr.dt_optimizer, tr.D_t, "Dt")
+    wrap_opt(tr.g_optimizer, tr.G, "G")
+    torch.randperm, torch.randn, torch.randint = w_perm, w_randn, w_randint
+    try:
+        tr.train()
+    finally:
+        torch.randperm, torch.randn, torch.randint = o_perm, o_randn, o_randint
+    # draws[randn][0] is fixed_z (trainer.py:195); per step afterwards: perm, randn, randint, perm
+    st["in.fixed_z"] = draws["randn"][0]
+    for s in range(steps):
+        st[f"in.perm_real.{s}"] = draws["randperm"][2 * s]
+        st[f"in.perm_fake.{s}"] = draws["randperm"][2 * s + 1]
+        st[f"in.z.{s}"] = draws["randn"][1 + s]
+        st[f"in.z_class.{s}"] = draws["randint"][s]
+        st[f"out.losses.{s}"] = np.array(losses[6 * s: 6 * s + 6], dtype=np.float64)
+        for tag in ("Ds", "Dt", "G"):
+            g, gsum, psum = snaps[tag][s]
+            for kk, v in g.items():
+                st[f"grad.{s}.{tag}.{kk}"] = v
+            keys = sorted(gsum)
+            st[f"meta.gsum_keys.{tag}"] = np.array(keys)
+            st[f"out.gsum.{s}.{tag}"] = np.array([gsum[kk] for kk in keys])
+            keys = sorted(psum)
+            st[f"meta.psum_keys.{tag}"] = np.array(keys)
+            st[f"out.psum.{s}.{tag}"] = np.array([psum[kk] for kk in keys])
+    put_state(st, "G.sd1", tr.G)
+    put_state(st, "Ds.sd1", tr.D_s)
+    put_state(st, "Dt.sd1", tr.D_t)
+    st["meta.cfg"] = np.array([ch, T, k, B, n_class, steps, z_dim], dtype=np.int64)
+    st["meta.lr"] = np.array(lr)
+    return st
+
+
+def f9_trainer_steps(R):
+    """Two full Trainer steps, hinge and wgan-gp, ch=2, T=8, k=4, B=2, 64x64.  Both runs use the
+    same seed, hence the same initial state / inputs / RNG draws: the wgan-gp file keeps only
+    its outputs and points at the hinge file for sd0 and the inputs."""
+    names = ("conv.0.cells.1.update_gate.weight", "conv.9.cells.2.out_gate.weight",
+             "conv.1.conv0.module.weight_bar", "conv.1.CBNorm1.embed.weight", "embedding.weight",
+             "colorize.module.weight_bar", "pre_conv.0.module.weight_bar", "attn.gamma",
+             "self_attn.gamma", "linear.module.weight_bar", "embed.module.weight_bar",
+             "res3d.conv1.module.weight_bar", "conv1.conv_sc.module.weight_bar")
+    ref = None
+    for loss in ("hinge", "wgan-gp"):
+        st = run_trainer(R, adv_loss=loss, ch=2, T=8, k=4, B=2, n_class=3, steps=2,
+                         seed=120, z_dim=16, lr=2e-3, grads_of=names)
+        if ref is None:
+            ref = st
+        else:
+            for k in list(st):
+                if ".sd0." in k or k.startswith("in."):
+                    assert np.array_equal(st[k], ref[k]), k
+                    del st[k]
+        save("f9_trainer_" + loss.replace("-", ""), st)
+
+
+def f10_config1(R):
+    """Config-1 plumbing (frames must be 64x64): T=16, B=2, n_class=1, k=8,
+    3 steps, hinge, reference defaults lr=5e-5 / z_dim=120; ch reduced from 8 to 2 so the
+    committed initial state_dict stays small.  Losses + checksums only."""
+    st = run_trainer(R, adv_loss="hinge", ch=2, T=16, k=8, B=2, n_class=1, steps=3, seed=140,
+                     z_dim=120, lr=5e-5, n_batches=1)   # one batch, re-iterated (trainer.py:216-221)
+    keep = {k: v for k, v in st.items() if not (k.startswith("grad.") or ".sd1." in k)}
+    save("f10_config1", keep)
+
+
+ALL = {"f1": f1_spectral_norm, "f2": f2_conditional_norm, "f3": f3_gresblock, "f4": f4_convgru,
+       "f5": f5_attention, "f6": f6_generator, "f7": f7_discriminators, "f8": f8_helpers,
+       "f9": f9_trainer_steps, "f10": f10_config1}
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    torch.use_deterministic_algorithms(False)
+    R = import_reference()
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        print(w)
+        ALL[w](R)
