@@ -1,0 +1,497 @@
+// Implicit-GEMM convolution (forward / backward-data) and backward-weight for gfx950.
+//
+// One workgroup = 256 threads = 4 waves computes a 128 x 128 output tile; each wave owns a
+// 64 x 64 quadrant as 2 x 2 MFMA 32x32 tiles (64 fp32 accumulator registers).  K is walked tap by
+// tap in 64-byte channel chunks (32 bf16 / 16 f32): the activation tile is GATHERED from the
+// channels-last tensor (shifted rows, zero outside the frame, optional nearest-x2 index map and
+// ReLU), so no im2col buffer ever exists.  Global -> registers -> LDS staging, two LDS buffers,
+// one barrier per K step; LDS rows are 64 B data + 16 B pad (80 B) which makes the ds_read_b128
+// fragment reads bank-conflict free.
+//
+//   bf16 : v_mfma_f32_32x32x16_bf16   (A: lane l holds row l&31, k = 8*(l>>5)..+7)
+//   f32  : v_mfma_f32_32x32x2_f32     (A: lane l holds row l&31, k = l>>5)        exact mode
+//   C/D  : col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int ROWB = 80;                 // bytes per LDS tile row
+constexpr int TILEB = BM * ROWB;         // 10240 B per operand tile
+constexpr int WG_LD = 132;               // f32 wgrad LDS row length in floats (128 + 4 pad)
+
+__device__ __forceinline__ u32x4 relu16_f32(u32x4 v) {
+    v.x = (int32_t)v.x < 0 ? 0u : v.x; v.y = (int32_t)v.y < 0 ? 0u : v.y;
+    v.z = (int32_t)v.z < 0 ? 0u : v.z; v.w = (int32_t)v.w < 0 ? 0u : v.w;
+    return v;
+}
+__device__ __forceinline__ uint32_t relu2_bf16(uint32_t v) {
+    uint32_t m = ((v >> 15) & 0x00010001u) * 0xffffu;      // 0xffff in each half whose sign bit is set
+    return v & ~m;
+}
+__device__ __forceinline__ u32x4 relu16_bf16(u32x4 v) {
+    v.x = relu2_bf16(v.x); v.y = relu2_bf16(v.y); v.z = relu2_bf16(v.z); v.w = relu2_bf16(v.w);
+    return v;
+}
+template <typename T> __device__ __forceinline__ u32x4 relu16(u32x4 v);
+template <> __device__ __forceinline__ u32x4 relu16<float>(u32x4 v) { return relu16_f32(v); }
+template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) { return relu16_bf16(v); }
+
+// acc[tm][tn] += A(64 rows of this wave) x B(64 cols of this wave) over one 64-byte K chunk.
+// As / Bs point at this lane's row (lane&31) of the wave's first 32-row sub-tile.
+template <typename T>
+__device__ __forceinline__ void mma_rowmajor(const char* As, const char* Bs, int lane, f32x16 (&acc)[2][2]) {
+    const int kh = lane >> 5;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int o = kk * 32 + kh * 16;
+            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + o);
+            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As + 32 * ROWB + o);
+            bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + o);
+            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs + 32 * ROWB + o);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int o = (kk * 2 + kh) * 4;
+            float a0 = *reinterpret_cast<const float*>(As + o);
+            float a1 = *reinterpret_cast<const float*>(As + 32 * ROWB + o);
+            float b0 = *reinterpret_cast<const float*>(Bs + o);
+            float b1 = *reinterpret_cast<const float*>(Bs + 32 * ROWB + o);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
+// ============================================================================ forward
+struct ConvK {
+    const char* in; const char* w; const float* bias; const char* res; const char* mask;
+    char* out; float* ws;
+    int M, C, ldi, Cout, ldo, ldres, ldmask;
+    int T, H, W, logH, logW, Hin, Win;
+    int kt, kh, kw, kchunks, nk, nsplit, tilesN;
+    int up2, relu_in, act, out_f32;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
+    constexpr int E16 = ElemTraits<T>::kPer16B;
+    constexpr int BK = 4 * E16;
+    __shared__ __attribute__((aligned(16))) char smem[2][2][TILEB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mt = blockIdx.x / p.tilesN, nt = blockIdx.x - mt * p.tilesN;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.z;
+    const int per = (p.nk + p.nsplit - 1) / p.nsplit;
+    const int k_begin = z * per;
+    const int k_end = min(p.nk, k_begin + per);
+
+    // ---- loader coordinates: this thread stages rows r0 and r0+64, 16-byte chunk q ----
+    const int q = tid & 3, r0 = tid >> 2;
+    int ax[2], ay[2], at[2], af[2];
+    bool av[2], bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        av[i] = m < p.M;
+        ax[i] = m & (p.W - 1);
+        ay[i] = (m >> p.logW) & (p.H - 1);
+        af[i] = m >> (p.logW + p.logH);
+        at[i] = p.kt > 1 ? af[i] % p.T : 0;
+        bv[i] = (n0 + r0 + 64 * i) < p.Cout;
+    }
+    // wave-uniform K-step state (tap decomposition kept incrementally)
+    int tap = 0, cc = 0, it = 0, iy = 0, ix = 0;
+    if (k_begin < k_end) {
+        tap = k_begin / p.kchunks; cc = k_begin - tap * p.kchunks;
+        it = tap / (p.kh * p.kw); const int rem = tap - it * p.kh * p.kw;
+        iy = rem / p.kw; ix = rem - iy * p.kw;
+    }
+    u32x4 ra[2], rb[2];
+    auto gload = [&]() {
+        const int dt = it - (p.kt >> 1), dy = iy - (p.kh >> 1), dx = ix - (p.kw >> 1);
+        const int c = cc * BK + q * E16;
+        const bool cv = c < p.C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int yy = ay[i] + dy, xx = ax[i] + dx;
+            const int tt = at[i] + dt;
+            const bool ok = av[i] && cv && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W &&
+                            (unsigned)tt < (unsigned)p.T;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                if (p.up2) { yy >>= 1; xx >>= 1; }
+                const size_t off = (((size_t)(af[i] + dt) * p.Hin + yy) * p.Win + xx) * (size_t)p.ldi + c;
+                v = *reinterpret_cast<const u32x4*>(p.in + off * sizeof(T));
+                if (p.relu_in) v = relu16<T>(v);
+            }
+            ra[i] = v;
+            u32x4 wv = {0u, 0u, 0u, 0u};
+            if (bv[i] && cv) {
+                const size_t off = ((size_t)tap * p.Cout + (n0 + r0 + 64 * i)) * (size_t)p.C + c;
+                wv = *reinterpret_cast<const u32x4*>(p.w + off * sizeof(T));
+            }
+            rb[i] = wv;
+        }
+        // advance to the next K step
+        if (++cc == p.kchunks) {
+            cc = 0; ++tap;
+            if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(&smem[buf][0][(r0 + 64 * i) * ROWB + q * 16]) = ra[i];
+            *reinterpret_cast<u32x4*>(&smem[buf][1][(r0 + 64 * i) * ROWB + q * 16]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (k_begin < k_end) {
+        gload();
+        lstore(0);
+        __syncthreads();
+        for (int ks = k_begin; ks < k_end; ++ks) {
+            const int buf = (ks - k_begin) & 1;
+            const bool more = ks + 1 < k_end;
+            if (more) gload();
+            mma_rowmajor<T>(&smem[buf][0][(wm * 64 + (lane & 31)) * ROWB],
+                            &smem[buf][1][(wn * 64 + (lane & 31)) * ROWB], lane, acc);
+            if (more) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    T* outT = reinterpret_cast<T*>(p.out);
+    float* outF = reinterpret_cast<float*>(p.out);
+    const T* resT = reinterpret_cast<const T*>(p.res);
+    const T* maskT = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
+            if (col >= p.Cout) continue;
+            const float bias = (!p.ws && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[tm][tn][r];
+                if (p.ws) {
+                    p.ws[((size_t)z * p.M + row) * p.Cout + col] = v;
+                } else {
+                    v += bias;
+                    if (resT) v += ldf(resT + (size_t)row * p.ldres + col);
+                    if (p.act == DVD_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == DVD_ACT_TANH) v = tanhf(v);
+                    else if (p.act == DVD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                    if (maskT && !(ldf(maskT + (size_t)row * p.ldmask + col) > 0.f)) v = 0.f;
+                    if (p.out_f32) outF[(size_t)row * p.ldo + col] = v;
+                    else stf(outT + (size_t)row * p.ldo + col, v);
+                }
+            }
+        }
+}
+
+// ============================================================================ backward-weight
+struct WgK {
+    const char* x; const char* dy; float* dw;
+    int M, C, ldx, Cin_real, Cout, Cy, ldy;
+    int T, H, W, logH, logW, Hin, Win;
+    int kt, kh, kw, up2, relu_in;
+    int tiles_co, tiles_ci, rows_per_split;
+    long long s_co, s_ci, s_tap;
+};
+
+// D[co][ci] = sum over rows m of dy[m][co] * x[pos(m)+tap][ci].  The reduction index (rows) is the
+// MFMA K dimension, so both operand tiles must be K(row)-contiguous per channel in LDS:
+//   bf16: each thread loads 2 channels x 8 consecutive rows as dwords, transposes them in
+//         registers (4 packed dwords per channel) and stores two 16-byte LDS rows;
+//   f32 : the natural [row][channel] image already matches the 32x32x2 fragment (1 float/lane).
+template <typename T>
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
+    constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr int BKW = kBf16 ? 32 : 16;            // rows reduced per step
+    __shared__ __attribute__((aligned(16))) char smem[2][2][TILEB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = p.tiles_co * p.tiles_ci;
+    const int tap = blockIdx.x / tiles;
+    const int rem = blockIdx.x - tap * tiles;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co0 = tco * BM, ci0 = tci * BN;
+    const int it = tap / (p.kh * p.kw), r2 = tap - it * p.kh * p.kw;
+    const int iy = r2 / p.kw, ix = r2 - iy * p.kw;
+    const int dt = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx = ix - (p.kw >> 1);
+    const int m_begin = blockIdx.z * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // shifted-row address of x for output row m, or -1 when outside the frame
+    auto xoff = [&](int m) -> long long {
+        if (m >= m_end) return -1;
+        int xx = (m & (p.W - 1)) + dx, yy = ((m >> p.logW) & (p.H - 1)) + dy_;
+        const int f = m >> (p.logW + p.logH);
+        const int tt = (p.kt > 1 ? f % p.T : 0) + dt;
+        if ((unsigned)yy >= (unsigned)p.H || (unsigned)xx >= (unsigned)p.W || (unsigned)tt >= (unsigned)p.T) return -1;
+        if (p.up2) { yy >>= 1; xx >>= 1; }
+        return (((long long)(f + dt) * p.Hin + yy) * p.Win + xx) * (long long)p.ldx;
+    };
+
+    if constexpr (kBf16) {
+        const int cp = tid & 63, pg = tid >> 6;          // channel pair, group of 8 rows
+        const int cy = co0 + 2 * cp, cx = ci0 + 2 * cp;
+        const bool cyv = cy < p.Cy, cxv = cx < p.C;
+        uint32_t dA[8], dB[8];
+        auto gload = [&](int mk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = mk + pg * 8 + j;
+                uint32_t a = 0u, b = 0u;
+                if (cyv && m < m_end) a = *reinterpret_cast<const uint32_t*>(p.dy + ((size_t)m * p.ldy + cy) * 2);
+                if (cxv) {
+                    const long long o = xoff(m);
+                    if (o >= 0) {
+                        b = *reinterpret_cast<const uint32_t*>(p.x + ((size_t)o + cx) * 2);
+                        if (p.relu_in) b = relu2_bf16(b);
+                    }
+                }
+                dA[j] = a; dB[j] = b;
+            }
+        };
+        auto lstore = [&](int buf) {
+            u32x4 lo, hi;
+            lo.x = (dA[0] & 0xffffu) | (dA[1] << 16); hi.x = (dA[0] >> 16) | (dA[1] & 0xffff0000u);
+            lo.y = (dA[2] & 0xffffu) | (dA[3] << 16); hi.y = (dA[2] >> 16) | (dA[3] & 0xffff0000u);
+            lo.z = (dA[4] & 0xffffu) | (dA[5] << 16); hi.z = (dA[4] >> 16) | (dA[5] & 0xffff0000u);
+            lo.w = (dA[6] & 0xffffu) | (dA[7] << 16); hi.w = (dA[6] >> 16) | (dA[7] & 0xffff0000u);
+            *reinterpret_cast<u32x4*>(&smem[buf][0][(2 * cp) * ROWB + pg * 16]) = lo;
+            *reinterpret_cast<u32x4*>(&smem[buf][0][(2 * cp + 1) * ROWB + pg * 16]) = hi;
+            lo.x = (dB[0] & 0xffffu) | (dB[1] << 16); hi.x = (dB[0] >> 16) | (dB[1] & 0xffff0000u);
+            lo.y = (dB[2] & 0xffffu) | (dB[3] << 16); hi.y = (dB[2] >> 16) | (dB[3] & 0xffff0000u);
+            lo.z = (dB[4] & 0xffffu) | (dB[5] << 16); hi.z = (dB[4] >> 16) | (dB[5] & 0xffff0000u);
+            lo.w = (dB[6] & 0xffffu) | (dB[7] << 16); hi.w = (dB[6] >> 16) | (dB[7] & 0xffff0000u);
+            *reinterpret_cast<u32x4*>(&smem[buf][1][(2 * cp) * ROWB + pg * 16]) = lo;
+            *reinterpret_cast<u32x4*>(&smem[buf][1][(2 * cp + 1) * ROWB + pg * 16]) = hi;
+        };
+        if (m_begin < m_end) {
+            gload(m_begin);
+            lstore(0);
+            __syncthreads();
+            int buf = 0;
+            for (int mk = m_begin; mk < m_end; mk += BKW, buf ^= 1) {
+                const bool more = mk + BKW < m_end;
+                if (more) gload(mk + BKW);
+                mma_rowmajor<T>(&smem[buf][0][(wm * 64 + (lane & 31)) * ROWB],
+                                &smem[buf][1][(wn * 64 + (lane & 31)) * ROWB], lane, acc);
+                if (more) lstore(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    } else {
+        // f32: LDS image [16 rows][WG_LD floats]; thread stages rows kr, kr+8, 16-byte chunk ch
+        const int ch = tid & 31, kr = tid >> 5;
+        const int cy = co0 + ch * 4, cx = ci0 + ch * 4;
+        const bool cyv = cy < p.Cy, cxv = cx < p.C;
+        u32x4 ra[2], rb[2];
+        auto gload = [&](int mk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = mk + kr + 8 * i;
+                u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+                if (cyv && m < m_end) a = *reinterpret_cast<const u32x4*>(p.dy + ((size_t)m * p.ldy + cy) * 4);
+                if (cxv) {
+                    const long long o = xoff(m);
+                    if (o >= 0) {
+                        b = *reinterpret_cast<const u32x4*>(p.x + ((size_t)o + cx) * 4);
+                        if (p.relu_in) b = relu16_f32(b);
+                    }
+                }
+                ra[i] = a; rb[i] = b;
+            }
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<u32x4*>(&smem[buf][0][((kr + 8 * i) * WG_LD + ch * 4) * 4]) = ra[i];
+                *reinterpret_cast<u32x4*>(&smem[buf][1][((kr + 8 * i) * WG_LD + ch * 4) * 4]) = rb[i];
+            }
+        };
+        auto mma = [&](int buf) {
+            const float* As = reinterpret_cast<const float*>(&smem[buf][0][0]) + wm * 64 + (lane & 31);
+            const float* Bs = reinterpret_cast<const float*>(&smem[buf][1][0]) + wn * 64 + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = kk * 2 + (lane >> 5);
+                const float a0 = As[k * WG_LD], a1 = As[k * WG_LD + 32];
+                const float b0 = Bs[k * WG_LD], b1 = Bs[k * WG_LD + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        };
+        if (m_begin < m_end) {
+            gload(m_begin);
+            lstore(0);
+            __syncthreads();
+            int buf = 0;
+            for (int mk = m_begin; mk < m_end; mk += BKW, buf ^= 1) {
+                const bool more = mk + BKW < m_end;
+                if (more) gload(mk + BKW);
+                mma(buf);
+                if (more) lstore(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int ci = ci0 + wn * 64 + tn * 32 + (lane & 31);
+            if (ci >= p.Cin_real) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                const float v = acc[tm][tn][r];
+                if (v != 0.f) atomicAdd(p.dw + co * p.s_co + ci * p.s_ci + tap * p.s_tap, v);
+            }
+        }
+}
+
+// ============================================================================ weight packing
+struct PackK {
+    const float* w; const float* sigma; char* wf; char* wd;
+    int Cout, Cin, ntaps, Cip, co_off, co_tot_f, co_tot_d, kt, kh, kw;
+};
+// one thread per (co, ci_pad, tap) of the forward pack; writes both packs
+template <typename T>
+__global__ void pack_weight_kernel(PackK p) {
+    const long long n = (long long)p.Cout * p.Cip * p.ntaps;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int tap = (int)(i % p.ntaps);
+    const long long r = i / p.ntaps;
+    const int ci = (int)(r % p.Cip), co = (int)(r / p.Cip);
+    float v = 0.f;
+    if (ci < p.Cin) {
+        v = p.w[((size_t)co * p.Cin + ci) * p.ntaps + tap];
+        if (p.sigma) v = v / *p.sigma;
+    }
+    if (p.wf) stf(reinterpret_cast<T*>(p.wf) + ((size_t)tap * p.co_tot_f + p.co_off + co) * p.Cip + ci, v);
+    if (p.wd) {
+        const int ftap = p.ntaps - 1 - tap;     // flipping every axis == reversing the flat tap index
+        stf(reinterpret_cast<T*>(p.wd) + ((size_t)ftap * p.Cip + ci) * p.co_tot_d + p.co_off + co, v);
+    }
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) {
+    if (!d || !d->in || !d->w || (!d->ws && (!d->out || d->nsplit > 1))) return DVD_E_ARG;
+    if (d->frames <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Cout <= 0) return DVD_E_ARG;
+    const int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
+    if (logH < 0 || logW < 0) return DVD_E_SHAPE;
+    if ((d->C & 7) || (d->ldi & 7) || !(d->kt & d->kh & d->kw & 1)) return DVD_E_SHAPE;
+    if (d->up2 && ((d->H | d->W) & 1)) return DVD_E_SHAPE;
+    if (d->kt > 1 && d->up2) return DVD_E_SHAPE;
+    const long long M = (long long)d->frames * d->T * d->H * d->W;
+    if (M >= (1ll << 31) - BM) return DVD_E_SHAPE;
+    ConvK p;
+    p.in = (const char*)d->in; p.w = (const char*)d->w; p.bias = d->bias; p.res = (const char*)d->res;
+    p.mask = (const char*)d->mask; p.out = (char*)d->out; p.ws = d->ws;
+    p.M = (int)M; p.C = d->C; p.ldi = d->ldi; p.Cout = d->Cout; p.ldo = d->ldo; p.ldres = d->ldres; p.ldmask = d->ldmask;
+    p.T = d->T; p.H = d->H; p.W = d->W; p.logH = logH; p.logW = logW;
+    p.Hin = d->up2 ? d->H / 2 : d->H; p.Win = d->up2 ? d->W / 2 : d->W;
+    p.kt = d->kt; p.kh = d->kh; p.kw = d->kw;
+    const int bk = d->dtype == DVD_BF16 ? 32 : 16;
+    p.kchunks = (d->C + bk - 1) / bk;
+    p.nk = d->kt * d->kh * d->kw * p.kchunks;
+    p.nsplit = d->nsplit < 1 ? 1 : d->nsplit;
+    if (p.nsplit > p.nk) p.nsplit = p.nk;
+    if (p.nsplit != (d->nsplit < 1 ? 1 : d->nsplit)) return DVD_E_ARG;   // caller sized ws for d->nsplit slabs
+    p.tilesN = (d->Cout + BN - 1) / BN;
+    p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
+    dim3 grid(cdiv(M, BM) * p.tilesN, 1, p.nsplit);
+    if (d->dtype == DVD_BF16) conv_igemm_kernel<bf16_t><<<grid, NT, 0, (hipStream_t)stream>>>(p);
+    else if (d->dtype == DVD_F32) conv_igemm_kernel<float><<<grid, NT, 0, (hipStream_t)stream>>>(p);
+    else return DVD_E_ARG;
+    return launch_status();
+}
+
+extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->dw) return DVD_E_ARG;
+    const int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
+    if (logH < 0 || logW < 0) return DVD_E_SHAPE;
+    if ((d->C & 7) || (d->ldx & 7) || (d->Cy & 7) || (d->ldy & 7) || !(d->kt & d->kh & d->kw & 1)) return DVD_E_SHAPE;
+    if (d->Cout > d->Cy || d->Cin_real > d->C) return DVD_E_ARG;
+    const long long M = (long long)d->frames * d->T * d->H * d->W;
+    if (M >= (1ll << 31) - 64) return DVD_E_SHAPE;
+    WgK p;
+    p.x = (const char*)d->x; p.dy = (const char*)d->dy; p.dw = d->dw;
+    p.M = (int)M; p.C = d->C; p.ldx = d->ldx; p.Cin_real = d->Cin_real; p.Cout = d->Cout; p.Cy = d->Cy; p.ldy = d->ldy;
+    p.T = d->T; p.H = d->H; p.W = d->W; p.logH = logH; p.logW = logW;
+    p.Hin = d->up2 ? d->H / 2 : d->H; p.Win = d->up2 ? d->W / 2 : d->W;
+    p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.up2 = d->up2; p.relu_in = d->relu_in;
+    p.tiles_co = (d->Cout + BM - 1) / BM; p.tiles_ci = (d->Cin_real + BN - 1) / BN;
+    p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap;
+    const int ntaps = d->kt * d->kh * d->kw;
+    long long msplit = d->msplit;
+    if (msplit < 1) {   // auto: enough workgroups to fill 256 CUs a few times over
+        const long long base = (long long)p.tiles_co * p.tiles_ci * ntaps;
+        msplit = (1024 + base - 1) / base;
+    }
+    long long rows = (M + msplit - 1) / msplit;
+    rows = (rows + 31) / 32 * 32;
+    if (rows < 32) rows = 32;
+    msplit = (M + rows - 1) / rows;
+    p.rows_per_split = (int)rows;
+    dim3 grid(p.tiles_co * p.tiles_ci * ntaps, 1, (unsigned)msplit);
+    if (d->dtype == DVD_BF16) conv_wgrad_kernel<bf16_t><<<grid, NT, 0, (hipStream_t)stream>>>(p);
+    else if (d->dtype == DVD_F32) conv_wgrad_kernel<float><<<grid, NT, 0, (hipStream_t)stream>>>(p);
+    else return DVD_E_ARG;
+    return launch_status();
+}
+
+extern "C" int dvd_pack_conv_weight(int dtype, const float* w, const float* sigma, int Cout, int Cin, int ntaps,
+                                    int Cip, int co_off, int co_tot_f, int co_tot_d, void* wf, void* wd,
+                                    int kt, int kh, int kw, void* stream) {
+    if (!w || (!wf && !wd) || Cout <= 0 || Cin <= 0 || ntaps != kt * kh * kw) return DVD_E_ARG;
+    if ((Cip & 7) || Cip < Cin || (wd && (co_tot_d & 7))) return DVD_E_SHAPE;
+    PackK p{w, sigma, (char*)wf, (char*)wd, Cout, Cin, ntaps, Cip, co_off, co_tot_f, co_tot_d, kt, kh, kw};
+    const long long n = (long long)Cout * Cip * ntaps;
+    if (dtype == DVD_BF16) pack_weight_kernel<bf16_t><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p);
+    else if (dtype == DVD_F32) pack_weight_kernel<float><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p);
+    else return DVD_E_ARG;
+    return launch_status();
+}

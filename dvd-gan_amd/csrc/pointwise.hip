@@ -1,0 +1,461 @@
+// Memory-bound kernels around the convolutions: batch-norm statistics, conditional batch norm
+// apply / backward, pooling / nearest resampling, bias-gradient column sums, small elementwise
+// helpers.  All of them move 16-byte (bf16) / 32-byte (f32) channel groups per thread and are
+// bounded by HBM bandwidth; statistics accumulate in fp64.
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- BN statistics
+// sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2          (fp64 atomics, caller zeroes)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, long long rows, int C, int ld, double* sums) {
+    __shared__ double red[256][17];
+    const int cg = (C + 7) / 8, nj = 256 / cg;
+    const int g = threadIdx.x % cg, j = threadIdx.x / cg;
+    double s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.0;
+    if (j < nj) {
+        for (long long r = (long long)blockIdx.x * nj + j; r < rows; r += (long long)gridDim.x * nj) {
+            float v[8];
+            load8<T>(x + (size_t)r * ld + g * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += (double)v[i] * v[i]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][8 + i] = q[i]; }
+    __syncthreads();
+    if (j == 0) {
+        for (int jj = 1; jj < nj; ++jj)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += red[jj * cg + g][i]; q[i] += red[jj * cg + g][8 + i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = g * 8 + i;
+            if (c < C) { atomicAdd(sums + c, s[i]); atomicAdd(sums + C + c, q[i]); }
+        }
+    }
+}
+
+// mean / rstd from the sums (training) or from the running buffers (eval); running-stat update.
+__global__ void bn_finalize_kernel(const double* sums, double n, int C, float eps, float momentum, int training,
+                                   float* mean, float* rstd, float* run_mean, float* run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (training) {
+        const double m = sums[c] / n;
+        double var = sums[C + c] / n - m * m;
+        if (var < 0) var = 0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {
+            const double unbiased = n > 1 ? var * n / (n - 1) : var;
+            run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
+            run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unbiased);
+        }
+    } else {
+        mean[c] = run_mean[c];
+        rstd[c] = (float)(1.0 / sqrt((double)run_var[c] + (double)eps));
+    }
+}
+
+// ----------------------------------------------------------------------------- CBN apply
+// y = act(gb[s][c] * (x - mean[c]) * rstd[c] + gb[s][C + c]),  s = samp[row / P]
+template <typename T>
+__global__ void cbn_apply_kernel(const T* x, T* y, long long rows, int P, int C, int ld, const float* mean,
+                                 const float* rstd, const float* gb, const int* samp, int relu) {
+    const int cg = ld / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cg) return;
+    const long long r = i / cg;
+    const int g = (int)(i - r * cg);
+    const float* gbs = gb + (size_t)samp[r / P] * 2 * C;
+    float v[8], o[8];
+    load8<T>(x + (size_t)r * ld + g * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = g * 8 + k;
+        float t = 0.f;
+        if (c < C) {
+            t = gbs[c] * ((v[k] - mean[c]) * rstd[c]) + gbs[C + c];
+            if (relu) t = fmaxf(t, 0.f);
+        }
+        o[k] = t;
+    }
+    store8<T>(y + (size_t)r * ld + g * 8, o);
+}
+
+// ----------------------------------------------------------------------------- CBN backward
+// dgb[s][c]   += sum gm * xhat,  dgb[s][C+c] += sum gm     with gm = g * (a > 0), over one frame
+template <typename T>
+__global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const T* g, const T* a, const T* x, int P, int C,
+                                                             int ld, const float* mean, const float* rstd,
+                                                             const int* samp, float* dgb, int relu, int chunk) {
+    __shared__ float red[256][17];
+    const int cg = (C + 7) / 8, nj = 256 / cg;
+    const int gi = threadIdx.x % cg, j = threadIdx.x / cg;
+    const int frame = blockIdx.y;
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    float dg[8], db[8], mu[8], rs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        dg[k] = db[k] = 0.f;
+        const int c = gi * 8 + k;
+        mu[k] = c < C ? mean[c] : 0.f;
+        rs[k] = c < C ? rstd[c] : 0.f;
+    }
+    if (j < nj) {
+        for (int p = p0 + j; p < p1; p += nj) {
+            const size_t off = ((size_t)frame * P + p) * ld + gi * 8;
+            float gv[8], av[8], xv[8];
+            load8<T>(g + off, gv);
+            load8<T>(x + off, xv);
+            if (relu) load8<T>(a + off, av);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gm = (!relu || av[k] > 0.f) ? gv[k] : 0.f;
+                dg[k] += gm * ((xv[k] - mu[k]) * rs[k]);
+                db[k] += gm;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[threadIdx.x][k] = dg[k]; red[threadIdx.x][8 + k] = db[k]; }
+    __syncthreads();
+    if (j == 0) {
+        for (int jj = 1; jj < nj; ++jj)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { dg[k] += red[jj * cg + gi][k]; db[k] += red[jj * cg + gi][8 + k]; }
+        float* o = dgb + (size_t)samp[frame] * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = gi * 8 + k;
+            if (c < C) { atomicAdd(o + c, dg[k]); atomicAdd(o + C + c, db[k]); }
+        }
+    }
+}
+
+// s12[c] = sum_s gb[s][c] * dgb[s][C+c]   (= sum dxhat),  s12[C+c] = sum_s gb[s][c] * dgb[s][c]  (= sum dxhat*xhat)
+__global__ void cbn_bwd_sums_kernel(const float* gb, const float* dgb, int B, int C, float* s12) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int s = 0; s < B; ++s) {
+        const double gam = gb[(size_t)s * 2 * C + c];
+        a += gam * dgb[(size_t)s * 2 * C + C + c];
+        b += gam * dgb[(size_t)s * 2 * C + c];
+    }
+    s12[c] = (float)a;
+    s12[C + c] = (float)b;
+}
+
+// dx = rstd * (gm * gamma_s - s1/N - xhat * s2/N)
+template <typename T>
+__global__ void cbn_bwd_apply_kernel(const T* g, const T* a, const T* x, T* dx, long long rows, int P, int C, int ld,
+                                     const float* mean, const float* rstd, const float* gb, const int* samp,
+                                     const float* s12, float inv_n, int relu) {
+    const int cg = ld / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cg) return;
+    const long long r = i / cg;
+    const int gi = (int)(i - r * cg);
+    const float* gbs = gb + (size_t)samp[r / P] * 2 * C;
+    const size_t off = (size_t)r * ld + gi * 8;
+    float gv[8], av[8], xv[8], o[8];
+    load8<T>(g + off, gv);
+    load8<T>(x + off, xv);
+    if (relu) load8<T>(a + off, av);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = gi * 8 + k;
+        float t = 0.f;
+        if (c < C) {
+            const float gm = (!relu || av[k] > 0.f) ? gv[k] : 0.f;
+            const float xh = (xv[k] - mean[c]) * rstd[c];
+            t = rstd[c] * (gm * gbs[c] - s12[c] * inv_n - xh * s12[C + c] * inv_n);
+        }
+        o[k] = t;
+    }
+    store8<T>(dx + off, o);
+}
+
+// ----------------------------------------------------------------------------- pooling / resampling
+// y[f][t][y][x][c] = scale * sum over the (pt x 2 x 2) window of x
+template <typename T>
+__global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld, int pt, float scale) {
+    const int cg = ld / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout * cg) return;
+    long long r = i / cg;
+    const int g = (int)(i - r * cg);
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int to = (int)(r % To);
+    const long long f = r / To;
+    const int Ti = To * pt, Hi = Ho * 2, Wi = Wo * 2;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int a = 0; a < pt; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int c = 0; c < 2; ++c) {
+                float v[8];
+                load8<T>(x + ((((size_t)f * Ti + to * pt + a) * Hi + yo * 2 + b) * Wi + xo * 2 + c) * ld + g * 8, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] *= scale;
+    store8<T>(y + (size_t)(i / cg) * ld + g * 8, acc);
+}
+// y[f][t][y][x][c] = scale * x[f][t/pt][y/2][x/2][c]
+template <typename T>
+__global__ void unpool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld, int pt, float scale) {
+    const int cg = ld / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout * cg) return;
+    long long r = i / cg;
+    const int g = (int)(i - r * cg);
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int to = (int)(r % To);
+    const long long f = r / To;
+    const int Ti = To / pt, Hi = Ho / 2, Wi = Wo / 2;
+    float v[8];
+    load8<T>(x + ((((size_t)f * Ti + to / pt) * Hi + yo / 2) * Wi + xo / 2) * ld + g * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= scale;
+    store8<T>(y + (size_t)(i / cg) * ld + g * 8, v);
+}
+
+// ----------------------------------------------------------------------------- column sums (bias grads)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long long rows, int C, int ld, float* out) {
+    __shared__ float red[256][9];
+    const int cg = (C + 7) / 8, nj = 256 / cg;
+    const int g = threadIdx.x % cg, j = threadIdx.x / cg;
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    if (j < nj)
+        for (long long r = (long long)blockIdx.x * nj + j; r < rows; r += (long long)gridDim.x * nj) {
+            float v[8];
+            load8<T>(x + (size_t)r * ld + g * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += v[i];
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = s[i];
+    __syncthreads();
+    if (j == 0) {
+        for (int jj = 1; jj < nj; ++jj)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += red[jj * cg + g][i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (g * 8 + i < C) atomicAdd(out + g * 8 + i, s[i]);
+    }
+}
+
+// ----------------------------------------------------------------------------- small elementwise
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* o, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float x[8], y[8];
+    load8<T>(a + i * 8, x);
+    load8<T>(b + i * 8, y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] += y[k];
+    store8<T>(o + i * 8, x);
+}
+template <typename T>
+__global__ void sum_leading_kernel(const T* in, T* out, int L, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int l = 0; l < L; ++l) {
+        float v[8];
+        load8<T>(in + ((size_t)l * n8 + i) * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+    store8<T>(out + i * 8, acc);
+}
+// dpre = dy * act'(y) expressed with the activation OUTPUT y (tanh: 1 - y^2, relu: y > 0)
+template <typename T>
+__global__ void act_bwd_kernel(const T* dy, const T* y, T* dx, long long n8, int act) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float g[8], v[8];
+    load8<T>(dy + i * 8, g);
+    load8<T>(y + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (act == DVD_ACT_TANH) g[k] *= 1.f - v[k] * v[k];
+        else if (act == DVD_ACT_RELU) g[k] = v[k] > 0.f ? g[k] : 0.f;
+        else if (act == DVD_ACT_SIGMOID) g[k] *= v[k] * (1.f - v[k]);
+    }
+    store8<T>(dx + i * 8, g);
+}
+
+// ----------------------------------------------------------------------------- reference-layout helpers
+// utils.py:77-83  src f32 [B][T][C][H][W] -> dst f32 [B][C][T][H/2][W/2]   (bwd: transpose of it)
+__global__ void vid_down_kernel(const float* src, float* dst, int B, int T, int C, int H, int W, int bwd) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long n = bwd ? (long long)B * T * C * H * W : (long long)B * C * T * Ho * Wo;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!bwd) {
+        long long r = i;
+        const int x = (int)(r % Wo); r /= Wo;
+        const int y = (int)(r % Ho); r /= Ho;
+        const int t = (int)(r % T); r /= T;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const float* s = src + ((((size_t)b * T + t) * C + c) * H + 2 * y) * W + 2 * x;
+        dst[i] = (s[0] + s[1] + s[W] + s[W + 1]) * 0.25f;
+    } else {   // src = d(dst of fwd) [B][C][T][Ho][Wo], dst = d(src of fwd) [B][T][C][H][W]
+        long long r = i;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int c = (int)(r % C); r /= C;
+        const int t = (int)(r % T);
+        const int b = (int)(r / T);
+        dst[i] = 0.25f * src[((((size_t)b * C + c) * T + t) * Ho + y / 2) * Wo + x / 2];
+    }
+}
+// dst row r = src row idx[r] (gather) or dst row idx[r] = src row r (scatter); rows of L floats
+__global__ void row_copy_kernel(const float* src, float* dst, const int* idx, long long nrows, long long L, int scatter) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * L) return;
+    const long long r = i / L, k = i - r * L;
+    if (scatter) dst[(size_t)idx[r] * L + k] = src[i];
+    else dst[i] = src[(size_t)idx[r] * L + k];
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+// run `body` with the storage type bound to T
+#define BY_DTYPE(dtype, ...)                                                   \
+    do {                                                                       \
+        if ((dtype) == DVD_BF16) { using T = bf16_t; __VA_ARGS__; }            \
+        else if ((dtype) == DVD_F32) { using T = float; __VA_ARGS__; }         \
+        else return DVD_E_ARG;                                                 \
+    } while (0)
+
+extern "C" int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int ld, double* sums, void* stream) {
+    if (!x || !sums || rows <= 0 || C <= 0) return DVD_E_ARG;
+    if ((ld & 7) || C > ld || (C + 7) / 8 > 256) return DVD_E_SHAPE;
+    const int nj = 256 / ((C + 7) / 8);
+    unsigned grid = cdiv(rows, (long long)nj * 8);
+    if (grid > 2048) grid = 2048;
+    BY_DTYPE(dtype, bn_stats_kernel<T><<<grid, 256, 0, S_>>>((const T*)x, rows, C, ld, sums));
+    return launch_status();
+}
+
+extern "C" int dvd_bn_finalize(const double* sums, long long rows, int C, float eps, float momentum, int training,
+                               float* mean, float* rstd, float* run_mean, float* run_var, void* stream) {
+    if (!mean || !rstd || C <= 0 || (training ? !sums : (!run_mean || !run_var))) return DVD_E_ARG;
+    bn_finalize_kernel<<<cdiv(C, 128), 128, 0, S_>>>(sums, (double)rows, C, eps, momentum, training, mean, rstd,
+                                                     run_mean, run_var);
+    return launch_status();
+}
+
+extern "C" int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames, int P, int C, int ld,
+                             const float* mean, const float* rstd, const float* gb, const int* samp, int relu,
+                             void* stream) {
+    if (!x || !y || !mean || !rstd || !gb || !samp || frames <= 0 || P <= 0) return DVD_E_ARG;
+    if ((ld & 7) || C > ld) return DVD_E_SHAPE;
+    const long long rows = frames * P, n = rows * (ld / 8);
+    BY_DTYPE(dtype, cbn_apply_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, rows, P, C, ld, mean, rstd,
+                                                                      gb, samp, relu));
+    return launch_status();
+}
+
+extern "C" int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames,
+                                int P, int C, int ld, const float* mean, const float* rstd, const float* gb,
+                                const int* samp, int B, float* dgb, float* s12, int relu, void* stream) {
+    if (!g || !x || !dx || !mean || !rstd || !gb || !samp || !dgb || !s12 || (relu && !a)) return DVD_E_ARG;
+    if (frames <= 0 || P <= 0 || B <= 0) return DVD_E_ARG;
+    if ((ld & 7) || C > ld || (C + 7) / 8 > 256) return DVD_E_SHAPE;
+    const int chunk = 2048;
+    dim3 grid(cdiv(P, chunk), (unsigned)frames);
+    BY_DTYPE(dtype, cbn_bwd_reduce_kernel<T><<<grid, 256, 0, S_>>>((const T*)g, (const T*)a, (const T*)x, P, C, ld,
+                                                                   mean, rstd, samp, dgb, relu, chunk));
+    cbn_bwd_sums_kernel<<<cdiv(C, 128), 128, 0, S_>>>(gb, dgb, B, C, s12);
+    const long long rows = frames * P, n = rows * (ld / 8);
+    const float inv_n = (float)(1.0 / (double)rows);
+    BY_DTYPE(dtype, cbn_bwd_apply_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)g, (const T*)a, (const T*)x,
+                                                                          (T*)dx, rows, P, C, ld, mean, rstd, gb,
+                                                                          samp, s12, inv_n, relu));
+    return launch_status();
+}
+
+// y = scale * sum over (pt,2,2) windows; output grid frames x To x Ho x Wo
+extern "C" int dvd_pool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt,
+                        float scale, void* stream) {
+    if (!x || !y || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || (pt != 1 && pt != 2)) return DVD_E_ARG;
+    if (ld & 7) return DVD_E_SHAPE;
+    const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
+    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale));
+    return launch_status();
+}
+// y[t][y][x] = scale * x[t/pt][y/2][x/2]; output grid frames x To x Ho x Wo
+extern "C" int dvd_unpool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt,
+                          float scale, void* stream) {
+    if (!x || !y || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || (pt != 1 && pt != 2)) return DVD_E_ARG;
+    if ((ld & 7) || (Ho & 1) || (Wo & 1) || (To % pt)) return DVD_E_SHAPE;
+    const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
+    BY_DTYPE(dtype, unpool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale));
+    return launch_status();
+}
+
+extern "C" int dvd_colsum(int dtype, const void* x, long long rows, int C, int ld, float* out, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0) return DVD_E_ARG;
+    if ((ld & 7) || C > ld || (C + 7) / 8 > 256) return DVD_E_SHAPE;
+    const int nj = 256 / ((C + 7) / 8);
+    unsigned grid = cdiv(rows, (long long)nj * 8);
+    if (grid > 1024) grid = 1024;
+    BY_DTYPE(dtype, colsum_kernel<T><<<grid, 256, 0, S_>>>((const T*)x, rows, C, ld, out));
+    return launch_status();
+}
+
+extern "C" int dvd_add(int dtype, const void* a, const void* b, void* out, long long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return DVD_E_ARG;
+    if (n & 7) return DVD_E_SHAPE;
+    BY_DTYPE(dtype, add_kernel<T><<<cdiv(n / 8, 256), 256, 0, S_>>>((const T*)a, (const T*)b, (T*)out, n / 8));
+    return launch_status();
+}
+extern "C" int dvd_sum_leading(int dtype, const void* in, void* out, int L, long long n, void* stream) {
+    if (!in || !out || n <= 0 || L <= 0) return DVD_E_ARG;
+    if (n & 7) return DVD_E_SHAPE;
+    BY_DTYPE(dtype, sum_leading_kernel<T><<<cdiv(n / 8, 256), 256, 0, S_>>>((const T*)in, (T*)out, L, n / 8));
+    return launch_status();
+}
+extern "C" int dvd_act_backward(int dtype, const void* dy, const void* y, void* dx, long long n, int act, void* stream) {
+    if (!dy || !y || !dx || n <= 0) return DVD_E_ARG;
+    if (n & 7) return DVD_E_SHAPE;
+    BY_DTYPE(dtype, act_bwd_kernel<T><<<cdiv(n / 8, 256), 256, 0, S_>>>((const T*)dy, (const T*)y, (T*)dx, n / 8, act));
+    return launch_status();
+}
+
+extern "C" int dvd_vid_downsample(const float* src, float* dst, int B, int T, int C, int H, int W, int backward,
+                                  void* stream) {
+    if (!src || !dst || B <= 0 || T <= 0 || C <= 0 || H <= 0 || W <= 0) return DVD_E_ARG;
+    if ((H | W) & 1) return DVD_E_SHAPE;
+    const long long n = backward ? (long long)B * T * C * H * W : (long long)B * C * T * (H / 2) * (W / 2);
+    vid_down_kernel<<<cdiv(n, 256), 256, 0, S_>>>(src, dst, B, T, C, H, W, backward);
+    return launch_status();
+}
+extern "C" int dvd_row_copy(const float* src, float* dst, const int* idx, long long nrows, long long L, int scatter,
+                            void* stream) {
+    if (!src || !dst || !idx || nrows <= 0 || L <= 0) return DVD_E_ARG;
+    row_copy_kernel<<<cdiv(nrows * L, 256), 256, 0, S_>>>(src, dst, idx, nrows, L, scatter);
+    return launch_status();
+}

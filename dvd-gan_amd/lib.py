@@ -1,0 +1,72 @@
+"""ctypes binding of libdvdgan_hip.so (include/dvdgan_hip.h).  Fails loudly: no fallback."""
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdvdgan_hip.so")
+_lib = None
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("frames", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("C", C.c_int), ("ldi", C.c_int), ("Cout", C.c_int), ("ldo", C.c_int),
+                ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("up2", C.c_int), ("relu_in", C.c_int),
+                ("nsplit", C.c_int), ("act", C.c_int), ("out_f32", C.c_int), ("ldres", C.c_int),
+                ("ldmask", C.c_int),
+                ("inp", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("mask", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("frames", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("C", C.c_int), ("ldx", C.c_int), ("Cin_real", C.c_int), ("Cout", C.c_int), ("Cy", C.c_int),
+                ("ldy", C.c_int), ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("up2", C.c_int),
+                ("relu_in", C.c_int), ("msplit", C.c_int),
+                ("s_co", C.c_longlong), ("s_ci", C.c_longlong), ("s_tap", C.c_longlong),
+                ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p)]
+
+
+def lib():
+    """The loaded shared library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(dvd_gan_amd has no CPU / eager fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.dvd_strerror.restype = C.c_char_p
+        if _lib.dvd_abi_version() != ABI_VERSION:
+            raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
+    return _lib
+
+
+ABI_VERSION = 1
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError(f"libdvdgan_hip: {lib().dvd_strerror(code).decode()} (code {code})")
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported storage dtype {t.dtype}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,119 @@
+"""GPU parity of the implicit-GEMM convolution kernels (forward, backward-data via the flipped
+pack, backward-weight) through the C ABI against a plain fp32 torch reference of the same op.
+
+Tolerances (rel-L2 = |a-b|_2 / |b|_2):
+  exact mode (f32 MFMA)                      <= 2e-6
+  bf16 mode vs reference on bf16-ROUNDED inputs, fp32 output   <= 2e-6  (only summation order differs)
+  bf16 mode vs the unrounded fp32 reference  <= 4e-3  
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def ref_conv(x, w, b=None, up2=False, relu_in=False):
+    if relu_in:
+        x = F.relu(x)
+    if up2:
+        x = F.interpolate(x, scale_factor=2)
+    pad = [k // 2 for k in w.shape[2:]]
+    return (F.conv3d if w.dim() == 5 else F.conv2d)(x, w, b, padding=pad)
+
+
+CASES = [
+    # frames, Cin, Cout, spatial, ksize, up2, relu_in
+    (3, 16, 24, (8, 8), (3, 3), False, False),
+    (5, 40, 136, (4, 4), (5, 5), False, False),
+    (2, 8, 8, (16, 16), (1, 1), False, True),
+    (4, 24, 40, (8, 8), (3, 3), True, True),
+    (2, 3, 16, (32, 32), (3, 3), False, False),      # 3 input channels padded to 8
+    (2, 16, 3, (16, 16), (3, 3), False, True),       # 3 output channels
+    (2, 8, 16, (6, 8, 8), (3, 3, 3), False, False),  # 3-D, T=6
+    (1, 16, 8, (4, 4, 4), (1, 1, 1), False, False),
+    (7, 136, 264, (4, 4), (3, 3), False, False),     # several K chunks, 3 N tiles, ragged M
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_forward_dgrad_wgrad(case, dtype):
+    from dvd_gan_amd import kern as K
+    F_, Cin, Cout, sp, ks, up2, relu_in = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(F_, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, *ks, generator=g) / (Cin * ks[-1] * ks[-2]) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    dev = "cuda"
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = ref_conv(xr, wr, b, up2, relu_in)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    # rounded-input reference for the tight bf16 check
+    exact = dtype == torch.float32
+    xq, wq, gyq = (x, w, gy) if exact else (bf(x), bf(w), bf(gy))
+    xq_ = xq.clone().requires_grad_(True)
+    wq_ = wq.clone().requires_grad_(True)
+    yq = ref_conv(xq_, wq_, b, up2, relu_in)
+    yq.backward(gyq)
+
+    xc = K.to_cl(x.to(dev), dtype)
+    pk = K.PackedConv(dtype, Cout, Cin, ks, dev).fill(w.to(dev))
+    # forward, fp32 output for the tight check
+    y = K.conv_forward(xc, pk.wf, ks, Cout, bias=b.to(dev), up2=up2, relu_in=relu_in, out_f32=True)
+    y_nc = K.from_cl(y, Cout).cpu()
+    assert rel(y_nc, yq.detach()) < 2e-6
+    assert rel(y_nc, y_ref.detach()) < (2e-6 if exact else 4e-3)
+    # split-K slabs sum to the same result (bias excluded)
+    nsplit = 3
+    ws = K.conv_forward(xc, pk.wf, ks, Cout, up2=up2, relu_in=relu_in, nsplit=nsplit, slabs=True)
+    y_split = ws.sum(0).view(*y.shape[:-1], Cout) + b.to(dev)
+    assert rel(y_split.cpu(), y_nc.movedim(1, -1)) < 2e-6
+    # storage-dtype output + tanh + residual + mask epilogue
+    res = torch.randn(y_ref.shape, generator=g)
+    msk = torch.randn(y_ref.shape, generator=g)
+    resc, mskc = K.to_cl(res.to(dev), dtype), K.to_cl(msk.to(dev), dtype)
+    y2 = K.conv_forward(xc, pk.wf, ks, Cout, bias=b.to(dev), res=resc, mask=mskc, act=2, up2=up2, relu_in=relu_in)
+    resq, mskq = (res, msk) if exact else (bf(res), bf(msk))
+    want = torch.tanh(yq.detach() + resq) * (mskq > 0)
+    assert rel(K.from_cl(y2, Cout).cpu(), want) < (2e-6 if exact else 3e-3)
+    if Cout % 8:
+        assert float(y2[..., Cout:].abs().max()) == 0.0     # pad channels stay zero
+
+    # backward-data = forward kernel on the flipped / transposed pack
+    gyc = K.to_cl(gy.to(dev), dtype)
+    dx = K.conv_forward(gyc, pk.wd, ks, pk.cip, out_f32=True)
+    dx_nc = K.from_cl(dx, Cin).cpu()
+    if up2:    # gradient of nearest x2 upsample = 2x2 sum
+        dx_nc = F.avg_pool2d(dx_nc, 2) * 4
+    if relu_in:
+        dx_nc = dx_nc * (xq > 0)
+    assert rel(dx_nc, xq_.grad) < 3e-6
+    assert rel(dx_nc, xr.grad) < (3e-6 if exact else 6e-3)
+
+    # backward-weight (fp32 atomics into the reference layout)
+    dw = torch.zeros(Cout, Cin, *ks, device=dev)
+    K.conv_wgrad(xc, gyc, dw, ks, Cout, Cin, up2=up2, relu_in=relu_in)
+    assert rel(dw.cpu(), wq_.grad) < 5e-6
+    assert rel(dw.cpu(), wr.grad) < (5e-6 if exact else 6e-3)
+    dw2 = torch.zeros_like(dw)
+    K.conv_wgrad(xc, gyc, dw2, ks, Cout, Cin, up2=up2, relu_in=relu_in, msplit=1)
+    assert rel(dw2.cpu(), wq_.grad) < 5e-6
+
+
+def test_bad_shapes_raise():
+    from dvd_gan_amd import kern as K
+    x = torch.zeros(1, 6, 8, 8, device="cuda")          # H=6 is not a power of two
+    pk = K.PackedConv(torch.float32, 8, 8, (3, 3), "cuda")
+    with pytest.raises(RuntimeError):
+        K.conv_forward(x, pk.wf, (3, 3), 8)
