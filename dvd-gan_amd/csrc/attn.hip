@@ -1,0 +1,215 @@
+// Per-frame 2-D self attention of the discriminators (Module/Discriminators.py:100-119):
+//     A = softmax_j(q_i . k_j)   (no 1/sqrt(d) scale),   out_i = sum_j A_ij v_j,   y = gamma*out + x
+// q|k|v come from ONE fused 1x1 convolution (columns [0,dq) | [koff,koff+dq) | [voff,voff+C) of
+// `qkv`).  N = H*W tokens per frame (256 / 64 at the 64x64 configuration), dq = C/8.
+// fp32 arithmetic on the vector pipe: the whole attention is < 0.2 % of the step's FLOPs, so the
+// kernels are organised for exactness and simple, coalesced access rather than MFMA.
+// A ([F][N][N] fp32) and out are kept for the backward pass.
+#include "common.h"
+
+namespace {
+
+constexpr int QB = 16;      // query rows per workgroup
+
+__device__ float blk_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* x,
+                                                       int ldx, int C, const float* gamma, T* y, T* att_out,
+                                                       float* A, int N) {
+    extern __shared__ float S[];                   // [QB][N]
+    const int f = blockIdx.y, i0 = blockIdx.x * QB, tid = threadIdx.x;
+    const T* qf = qkv + (size_t)f * N * ldq;
+    // ---- scores ----
+    for (int idx = tid; idx < QB * N; idx += 256) {
+        const int i = idx / N, j = idx - i * N;
+        float s = 0.f;
+        if (i0 + i < N) {
+            const T* q = qf + (size_t)(i0 + i) * ldq;
+            const T* k = qf + (size_t)j * ldq + koff;
+            for (int d = 0; d < dq; ++d) s += ldf(q + d) * ldf(k + d);
+        }
+        S[idx] = s;
+    }
+    __syncthreads();
+    // ---- row softmax (one wave per row) ----
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = wave; i < QB; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < N; j += 64) m = fmaxf(m, S[i * N + j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j < N; j += 64) { const float e = expf(S[i * N + j] - m); S[i * N + j] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int j = lane; j < N; j += 64) {
+            const float a = S[i * N + j] * inv;
+            S[i * N + j] = a;
+            if (A && i0 + i < N) A[((size_t)f * N + i0 + i) * N + j] = a;
+        }
+    }
+    __syncthreads();
+    // ---- out = A v, 4 rows per thread ----
+    const float g = *gamma;
+    for (int idx = tid; idx < (QB / 4) * C; idx += 256) {
+        const int ib = (idx / C) * 4, c = idx % C;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < N; ++j) {
+            const float vv = ldf(qf + (size_t)j * ldq + voff + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += S[(ib + r) * N + j] * vv;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + ib + r;
+            if (i >= N) continue;
+            const size_t o = ((size_t)f * N + i) * ldx + c;
+            if (att_out) stf(att_out + o, acc[r]);
+            stf(y + o, g * acc[r] + ldf(x + o));
+        }
+    }
+}
+
+// Backward, row pass: dA, dS (written over `dS` [F][N][N]), dq, dgamma.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* dy,
+                                                            int ldx, int C, const float* gamma, const T* att_out,
+                                                            const float* A, float* dS, T* dqkv, float* dgamma, int N) {
+    extern __shared__ float S[];                   // [QB][N] dA -> dS
+    __shared__ float sh[4];
+    const int f = blockIdx.y, i0 = blockIdx.x * QB, tid = threadIdx.x;
+    const T* qf = qkv + (size_t)f * N * ldq;
+    const float g = *gamma;
+    // dgamma partial: sum dy * att_out over this block's rows
+    float dgp = 0.f;
+    for (int idx = tid; idx < QB * C; idx += 256) {
+        const int i = i0 + idx / C, c = idx % C;
+        if (i < N) {
+            const size_t o = ((size_t)f * N + i) * ldx + c;
+            dgp += ldf(dy + o) * ldf(att_out + o);
+        }
+    }
+    dgp = blk_sum(dgp, sh);
+    if (tid == 0 && dgamma) atomicAdd(dgamma, dgp);
+    // dA[i][j] = gamma * sum_c dy[i][c] v[j][c]
+    for (int idx = tid; idx < QB * N; idx += 256) {
+        const int i = idx / N, j = idx - i * N;
+        float s = 0.f;
+        if (i0 + i < N) {
+            const T* d = dy + ((size_t)f * N + i0 + i) * ldx;
+            const T* v = qf + (size_t)j * ldq + voff;
+            for (int c = 0; c < C; ++c) s += ldf(d + c) * ldf(v + c);
+        }
+        S[idx] = s * g;
+    }
+    __syncthreads();
+    // dS = A * (dA - sum_j A dA)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = wave; i < QB; i += 4) {
+        if (i0 + i >= N) continue;
+        const float* a = A + ((size_t)f * N + i0 + i) * N;
+        float dot = 0.f;
+        for (int j = lane; j < N; j += 64) dot += a[j] * S[i * N + j];
+        dot = wave_sum(dot);
+        for (int j = lane; j < N; j += 64) {
+            const float v = a[j] * (S[i * N + j] - dot);
+            S[i * N + j] = v;
+            dS[((size_t)f * N + i0 + i) * N + j] = v;
+        }
+    }
+    __syncthreads();
+    // dq[i][d] = sum_j dS[i][j] k[j][d]
+    for (int idx = tid; idx < QB * dq; idx += 256) {
+        const int i = idx / dq, d = idx - i * dq;
+        if (i0 + i >= N) continue;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += S[i * N + j] * ldf(qf + (size_t)j * ldq + koff + d);
+        stf(dqkv + ((size_t)f * N + i0 + i) * ldq + d, s);
+    }
+}
+
+// Backward, column pass: dv[j][c] = gamma * sum_i A[i][j] dy[i][c];  dk[j][d] = sum_i dS[i][j] q[i][d]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* dy,
+                                                            int ldx, int C, const float* gamma, const float* A,
+                                                            const float* dS, T* dqkv, int N) {
+    extern __shared__ float S[];                   // [N][QB] slice of A, then of dS (column block j0..j0+QB)
+    const int f = blockIdx.y, j0 = blockIdx.x * QB, tid = threadIdx.x;
+    const T* qf = qkv + (size_t)f * N * ldq;
+    const float g = *gamma;
+    for (int idx = tid; idx < N * QB; idx += 256) {
+        const int i = idx / QB, jj = idx - i * QB;
+        S[idx] = (j0 + jj < N) ? A[((size_t)f * N + i) * N + j0 + jj] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < (QB / 4) * C; idx += 256) {
+        const int jb = (idx / C) * 4, c = idx % C;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < N; ++i) {
+            const float d = ldf(dy + ((size_t)f * N + i) * ldx + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += S[i * QB + jb + r] * d;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (j0 + jb + r < N) stf(dqkv + ((size_t)f * N + j0 + jb + r) * ldq + voff + c, g * acc[r]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * QB; idx += 256) {
+        const int i = idx / QB, jj = idx - i * QB;
+        S[idx] = (j0 + jj < N) ? dS[((size_t)f * N + i) * N + j0 + jj] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < QB * dq; idx += 256) {
+        const int jj = idx / dq, d = idx - jj * dq;
+        if (j0 + jj >= N) continue;
+        float s = 0.f;
+        for (int i = 0; i < N; ++i) s += S[i * QB + jj] * ldf(qf + (size_t)i * ldq + d);
+        stf(dqkv + ((size_t)f * N + j0 + jj) * ldq + koff + d, s);
+    }
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+#define BY_DTYPE(dtype, ...)                                                   \
+    do {                                                                       \
+        if ((dtype) == DVD_BF16) { using T = bf16_t; __VA_ARGS__; }            \
+        else if ((dtype) == DVD_F32) { using T = float; __VA_ARGS__; }         \
+        else return DVD_E_ARG;                                                 \
+    } while (0)
+
+extern "C" int dvd_attention_forward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* x,
+                                     int ldx, int C, const float* gamma, void* y, void* att_out, float* A,
+                                     long long frames, int N, void* stream) {
+    if (!qkv || !x || !gamma || !y || frames <= 0 || N <= 0 || dq <= 0 || C <= 0) return DVD_E_ARG;
+    if ((size_t)QB * N * sizeof(float) > 64 * 1024 || frames > 65535) return DVD_E_SHAPE;
+    dim3 grid(cdiv(N, QB), (unsigned)frames);
+    const size_t sh = (size_t)QB * N * sizeof(float);
+    BY_DTYPE(dtype, attn_fwd_kernel<T><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)x, ldx, C, gamma,
+                                                              (T*)y, (T*)att_out, A, N));
+    return launch_status();
+}
+
+extern "C" int dvd_attention_backward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* dy,
+                                      int ldx, int C, const float* gamma, const void* att_out, const float* A,
+                                      float* dS, void* dqkv, float* dgamma, long long frames, int N, void* stream) {
+    if (!qkv || !dy || !gamma || !att_out || !A || !dS || !dqkv || frames <= 0 || N <= 0) return DVD_E_ARG;
+    if ((size_t)QB * N * sizeof(float) > 64 * 1024 || frames > 65535) return DVD_E_SHAPE;
+    dim3 grid(cdiv(N, QB), (unsigned)frames);
+    const size_t sh = (size_t)QB * N * sizeof(float);
+    BY_DTYPE(dtype, attn_bwd_rows_kernel<T><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)dy, ldx, C,
+                                                                   gamma, (const T*)att_out, A, dS, (T*)dqkv, dgamma, N));
+    BY_DTYPE(dtype, attn_bwd_cols_kernel<T><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)dy, ldx, C,
+                                                                   gamma, A, dS, (T*)dqkv, N));
+    return launch_status();
+}

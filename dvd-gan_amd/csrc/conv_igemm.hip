@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
 // ============================================================================ weight packing
 struct PackK {
     const float* w; const float* sigma; char* wf; char* wd;
-    int Cout, Cin, ntaps, Cip, co_off, co_tot_f, co_tot_d, kt, kh, kw;
+    int Cout, Cin, ntaps, Cip, co_off, co_tot_f, co_tot_d, kt, kh, kw, ci_off, ci_tot;
 };
 // one thread per (co, ci_pad, tap) of the forward pack; writes both packs
 template <typename T>
@@ -404,7 +404,7 @@ __global__ void pack_weight_kernel(PackK p) {
     const int ci = (int)(r % p.Cip), co = (int)(r / p.Cip);
     float v = 0.f;
     if (ci < p.Cin) {
-        v = p.w[((size_t)co * p.Cin + ci) * p.ntaps + tap];
+        v = p.w[((size_t)co * p.ci_tot + p.ci_off + ci) * p.ntaps + tap];
         if (p.sigma) v = v / *p.sigma;
     }
     if (p.wf) stf(reinterpret_cast<T*>(p.wf) + ((size_t)tap * p.co_tot_f + p.co_off + co) * p.Cip + ci, v);
@@ -485,10 +485,12 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
 
 extern "C" int dvd_pack_conv_weight(int dtype, const float* w, const float* sigma, int Cout, int Cin, int ntaps,
                                     int Cip, int co_off, int co_tot_f, int co_tot_d, void* wf, void* wd,
-                                    int kt, int kh, int kw, void* stream) {
+                                    int kt, int kh, int kw, int ci_off, int ci_tot, void* stream) {
     if (!w || (!wf && !wd) || Cout <= 0 || Cin <= 0 || ntaps != kt * kh * kw) return DVD_E_ARG;
+    if (ci_tot <= 0) { ci_off = 0; ci_tot = Cin; }
+    if (ci_off < 0 || ci_off + Cin > ci_tot) return DVD_E_ARG;
     if ((Cip & 7) || Cip < Cin || (wd && (co_tot_d & 7))) return DVD_E_SHAPE;
-    PackK p{w, sigma, (char*)wf, (char*)wd, Cout, Cin, ntaps, Cip, co_off, co_tot_f, co_tot_d, kt, kh, kw};
+    PackK p{w, sigma, (char*)wf, (char*)wd, Cout, Cin, ntaps, Cip, co_off, co_tot_f, co_tot_d, kt, kh, kw, ci_off, ci_tot};
     const long long n = (long long)Cout * Cip * ntaps;
     if (dtype == DVD_BF16) pack_weight_kernel<bf16_t><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p);
     else if (dtype == DVD_F32) pack_weight_kernel<float><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p);

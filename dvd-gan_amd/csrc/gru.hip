@@ -1,0 +1,284 @@
+// ConvGRU layer: the serial (time-recurrent) half of Module/ConvGRU.py:29-54 for one layer and
+// all T steps, forward and BPTT.
+//
+// The reference evaluates three convolutions per cell-step on cat[x, h].  Here each gate conv is
+// split by linearity into its x-part and its h-part:
+//     conv(cat[x, h]) = conv_x(x) + conv_h(h)
+// The x-parts of all three gates and all T steps do not depend on the recurrence; the caller
+// computes them as ONE large batched convolution (gx[t] = Wx * x_t + b, columns u|r|o).  Only the
+// h-parts remain on the serial chain and are driven from here, without returning to Python:
+//     step t :  [u|r] = sigmoid(gx[t][u|r] + conv(h_{t-1}; Wh_ur))        (one N=2h conv)
+//               o     = tanh   (gx[t][o]   + conv(h_{t-1}*r; Wh_o))
+//               h_t   = h_{t-1}*(1-u) + o*u                                ConvGRU.py:47-52
+// Small spatial sizes (4x4, 8x8) give few output tiles, so these convs run split-K and the gate
+// kernels below reduce the fp32 slabs while applying the non-linearities.
+// Backward walks t = T-1..0 with two backward-data convs per step; every weight gradient and the
+// x-path gradient are batched over all T by the caller afterwards (dg holds d(pre-activation)).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+template <typename T> __device__ __forceinline__ float round_to(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// u, r, hr for one step.  ws: [ns][M][2h] fp32 partial sums of conv(h_prev; Wh_ur) (ns may be 0).
+template <typename T>
+__global__ void gru_gates_ur_kernel(const float* ws, int ns, const T* gx, int ldg, const T* hprev, T* u, T* r, T* hr,
+                                    long long M, int h) {
+    const int cg = h / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cg) return;
+    const long long row = i / cg;
+    const int c = (int)(i - row * cg) * 8;
+    float pu[8], pr[8], hp[8];
+    load8<T>(gx + (size_t)row * ldg + c, pu);
+    load8<T>(gx + (size_t)row * ldg + h + c, pr);
+    for (int s = 0; s < ns; ++s) {
+        float a[8], b[8];
+        const float* w = ws + ((size_t)s * M + row) * 2 * h;
+        load8<float>(w + c, a);
+        load8<float>(w + h + c, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { pu[k] += a[k]; pr[k] += b[k]; }
+    }
+    if (hprev) load8<T>(hprev + (size_t)row * h + c, hp);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        pu[k] = sigmoidf_(pu[k]);
+        pr[k] = round_to<T>(sigmoidf_(pr[k]));       // the stored r is the r the cell uses
+        hp[k] = hprev ? hp[k] * pr[k] : 0.f;
+    }
+    store8<T>(u + (size_t)row * h + c, pu);
+    store8<T>(r + (size_t)row * h + c, pr);
+    store8<T>(hr + (size_t)row * h + c, hp);
+}
+
+// o, h_t.  ws: [ns][M][h] partial sums of conv(h_prev*r; Wh_o).  h32p/h32n: optional fp32 carry.
+template <typename T>
+__global__ void gru_out_kernel(const float* ws, int ns, const T* gx, int ldg, const T* hprev, const float* h32p,
+                               const T* u, T* o, T* hn, float* h32n, long long M, int h) {
+    const int cg = h / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cg) return;
+    const long long row = i / cg;
+    const int c = (int)(i - row * cg) * 8;
+    float po[8], hp[8], uu[8];
+    load8<T>(gx + (size_t)row * ldg + 2 * h + c, po);
+    for (int s = 0; s < ns; ++s) {
+        float a[8];
+        load8<float>(ws + ((size_t)s * M + row) * h + c, a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) po[k] += a[k];
+    }
+    if (h32p) load8<float>(h32p + (size_t)row * h + c, hp);
+    else if (hprev) load8<T>(hprev + (size_t)row * h + c, hp);
+    else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hp[k] = 0.f;
+    }
+    load8<T>(u + (size_t)row * h + c, uu);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        po[k] = round_to<T>(tanhf(po[k]));
+        hp[k] = hp[k] * (1.f - uu[k]) + po[k] * uu[k];
+    }
+    store8<T>(o + (size_t)row * h + c, po);
+    store8<T>(hn + (size_t)row * h + c, hp);
+    if (h32n) store8<float>(h32n + (size_t)row * h + c, hp);
+}
+
+// BPTT, first half of step t: dh = dh_out[t] + carry + sum(slabs);  writes d(pre_u), d(pre_o), new carry.
+template <typename T>
+__global__ void gru_bwd_out_kernel(const T* dh_out, float* carry, const float* ws, int ns, const T* u, const T* o,
+                                   const T* hprev, T* dg, int ldg, long long M, int h) {
+    const int cg = h / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cg) return;
+    const long long row = i / cg;
+    const int c = (int)(i - row * cg) * 8;
+    const size_t off = (size_t)row * h + c;
+    float dh[8], t8[8], uu[8], oo[8], hp[8], dpu[8], dpo[8];
+    load8<float>(carry + off, dh);
+    if (dh_out) {
+        load8<T>(dh_out + off, t8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dh[k] += t8[k];
+    }
+    for (int s = 0; s < ns; ++s) {
+        load8<float>(ws + ((size_t)s * M + row) * h + c, t8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dh[k] += t8[k];
+    }
+    load8<T>(u + off, uu);
+    load8<T>(o + off, oo);
+    if (hprev) load8<T>(hprev + off, hp);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float hpk = hprev ? hp[k] : 0.f;
+        dpo[k] = dh[k] * uu[k] * (1.f - oo[k] * oo[k]);
+        dpu[k] = dh[k] * (oo[k] - hpk) * uu[k] * (1.f - uu[k]);
+        dh[k] = dh[k] * (1.f - uu[k]);
+    }
+    store8<float>(carry + off, dh);
+    store8<T>(dg + (size_t)row * ldg + c, dpu);
+    store8<T>(dg + (size_t)row * ldg + 2 * h + c, dpo);
+}
+
+// BPTT, second half: d(h*r) = sum(slabs);  carry += d(hr)*r;  d(pre_r) = d(hr)*h_prev*r(1-r).
+template <typename T>
+__global__ void gru_bwd_r_kernel(float* carry, const float* ws, int ns, const T* r, const T* hprev, T* dg, int ldg,
+                                 long long M, int h) {
+    const int cg = h / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cg) return;
+    const long long row = i / cg;
+    const int c = (int)(i - row * cg) * 8;
+    const size_t off = (size_t)row * h + c;
+    float dhr[8], t8[8], rr[8], hp[8], cy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dhr[k] = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        load8<float>(ws + ((size_t)s * M + row) * h + c, t8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dhr[k] += t8[k];
+    }
+    if (hprev) {
+        load8<T>(r + off, rr);
+        load8<T>(hprev + off, hp);
+        load8<float>(carry + off, cy);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cy[k] += dhr[k] * rr[k];
+            dhr[k] = dhr[k] * hp[k] * rr[k] * (1.f - rr[k]);
+        }
+        store8<float>(carry + off, cy);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dhr[k] = 0.f;
+    }
+    store8<T>(dg + (size_t)row * ldg + h + c, dhr);
+}
+
+// out = carry + sum(slabs): gradient wrt the supplied initial hidden state
+__global__ void gru_dh0_kernel(const float* carry, const float* ws, int ns, float* out, long long M, int h) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * h) return;
+    float v = carry[i];
+    for (int s = 0; s < ns; ++s) v += ws[(size_t)s * M * h + i];
+    out[i] = v;
+}
+
+int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, int Cout,
+               int nsplit, float* ws, void* stream) {
+    dvd_conv_desc d = {};
+    d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = ldi; d.Cout = Cout; d.ldo = Cout;
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = nsplit; d.in = in; d.w = w; d.ws = ws;
+    return dvd_conv_forward(&d, stream);
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+#define BY_DTYPE(dtype, ...)                                                   \
+    do {                                                                       \
+        if ((dtype) == DVD_BF16) { using T = bf16_t; __VA_ARGS__; }            \
+        else if ((dtype) == DVD_F32) { using T = float; __VA_ARGS__; }         \
+        else return DVD_E_ARG;                                                 \
+    } while (0)
+
+// Split-K factor that brings a conv with few output tiles up to ~one workgroup per CU.
+extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps) {
+    const int bk = dtype == DVD_BF16 ? 32 : 16;
+    const long long nk = (long long)ntaps * ((C + bk - 1) / bk);
+    const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    long long ns = (256 + tiles - 1) / tiles;
+    if (ns > 16) ns = 16;
+    if (ns > nk) ns = nk;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
+    if (!d || !d->gx || !d->w_ur || !d->w_o || !d->h_all || !d->u_all || !d->r_all || !d->o_all || !d->hr_all || !d->ws)
+        return DVD_E_ARG;
+    if (d->T <= 0 || d->B <= 0 || d->hidden <= 0 || !(d->k & 1)) return DVD_E_ARG;
+    if (d->hidden & 7) return DVD_E_SHAPE;
+    const int h = d->hidden, ntaps = d->k * d->k;
+    const long long M = (long long)d->B * d->H * d->W;
+    const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
+    const size_t step = (size_t)M * h * esz;
+    const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, 2 * h, h, ntaps);
+    const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);
+    const unsigned grid = cdiv(M * (h / 8), 256);
+    for (int t = 0; t < d->T; ++t) {
+        const char* hprev = t > 0 ? (const char*)d->h_all + (t - 1) * step : (const char*)d->h0;
+        const char* gx = (const char*)d->gx + (size_t)t * d->gx_stride * esz;
+        char* u = (char*)d->u_all + t * step; char* r = (char*)d->r_all + t * step;
+        char* o = (char*)d->o_all + t * step; char* hr = (char*)d->hr_all + t * step;
+        char* hn = (char*)d->h_all + t * step;
+        const float* h32p = (d->h32 && t > 0) ? d->h32 + (size_t)(t & 1) * M * h : nullptr;
+        float* h32n = d->h32 ? d->h32 + (size_t)((t + 1) & 1) * M * h : nullptr;
+        int rc, ns = 0;
+        if (hprev) {
+            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hprev, h, h, d->w_ur, 2 * h, ns_ur, d->ws, stream);
+            if (rc) return rc;
+            ns = ns_ur;
+        }
+        BY_DTYPE(d->dtype, gru_gates_ur_kernel<T><<<grid, 256, 0, S_>>>(d->ws, ns, (const T*)gx, 3 * h, (const T*)hprev,
+                                                                        (T*)u, (T*)r, (T*)hr, M, h));
+        ns = 0;
+        if (hprev) {
+            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hr, h, h, d->w_o, h, ns_o, d->ws, stream);
+            if (rc) return rc;
+            ns = ns_o;
+        }
+        BY_DTYPE(d->dtype, gru_out_kernel<T><<<grid, 256, 0, S_>>>(d->ws, ns, (const T*)gx, 3 * h, (const T*)hprev, h32p,
+                                                                   (const T*)u, (T*)o, (T*)hn, h32n, M, h));
+    }
+    return launch_status();
+}
+
+extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
+    if (!d || !d->wd_ur || !d->wd_o || !d->h_all || !d->u_all || !d->r_all || !d->o_all || !d->dg || !d->carry || !d->ws)
+        return DVD_E_ARG;
+    if (d->T <= 0 || d->B <= 0 || d->hidden <= 0 || !(d->k & 1)) return DVD_E_ARG;
+    if (d->hidden & 7) return DVD_E_SHAPE;
+    const int h = d->hidden, ntaps = d->k * d->k;
+    const long long M = (long long)d->B * d->H * d->W;
+    const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
+    const size_t step = (size_t)M * h * esz;
+    const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);        // d(hr)  = convT(d pre_o)
+    const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, h, 2 * h, ntaps);   // dh    += convT(d pre_u | d pre_r)
+    const unsigned grid = cdiv(M * (h / 8), 256);
+    hipError_t e = hipMemsetAsync(d->carry, 0, (size_t)M * h * sizeof(float), S_);
+    if (e != hipSuccess) return DVD_E_LAUNCH;
+    int ns_pending = 0;      // slabs of the ur backward-data conv of step t+1 waiting in ws
+    for (int t = d->T - 1; t >= 0; --t) {
+        const char* hprev = t > 0 ? (const char*)d->h_all + (t - 1) * step : (const char*)d->h0;
+        const char* u = (const char*)d->u_all + t * step; const char* r = (const char*)d->r_all + t * step;
+        const char* o = (const char*)d->o_all + t * step;
+        const char* dho = d->dh_out ? (const char*)d->dh_out + t * step : nullptr;
+        char* dg = (char*)d->dg + (size_t)t * M * 3 * h * esz;
+        BY_DTYPE(d->dtype, gru_bwd_out_kernel<T><<<grid, 256, 0, S_>>>((const T*)dho, d->carry, d->ws, ns_pending,
+                                                                       (const T*)u, (const T*)o, (const T*)hprev,
+                                                                       (T*)dg, 3 * h, M, h));
+        ns_pending = 0;
+        int ns = 0, rc;
+        if (hprev) {
+            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, h, ns_o, d->ws,
+                            stream);
+            if (rc) return rc;
+            ns = ns_o;
+        }
+        BY_DTYPE(d->dtype, gru_bwd_r_kernel<T><<<grid, 256, 0, S_>>>(d->carry, d->ws, ns, (const T*)r, (const T*)hprev,
+                                                                     (T*)dg, 3 * h, M, h));
+        if (hprev) {
+            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, h, ns_ur, d->ws, stream);
+            if (rc) return rc;
+            ns_pending = ns_ur;
+        }
+    }
+    if (d->dh0) gru_dh0_kernel<<<cdiv(M * h, 256), 256, 0, S_>>>(d->carry, d->ws, ns_pending, d->dh0, M, h);
+    return launch_status();
+}

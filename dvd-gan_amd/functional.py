@@ -1,0 +1,386 @@
+"""torch.autograd.Function wrappers: each forward / backward is a short sequence of C-ABI kernel
+launches on the current HIP stream.  Tensors between them are channels-last device tensors in the
+storage dtype (torch.float32 = exact mode, torch.bfloat16); parameters and their gradients are
+fp32 in the reference layouts, so torch.optim / checkpoints see exactly the reference tensors.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import kern as K
+from . import lib as L
+
+
+# ------------------------------------------------------------------ boundary layout
+class ToChannelsLast(Function):
+    """fp32 [F, C, *spatial] -> [F', *spatial, pad8(C)]   (swap=(A,B): frame (a,b) -> (b,a))"""
+
+    @staticmethod
+    def forward(ctx, x, dtype, swap):
+        ctx.channels, ctx.swap = x.shape[1], swap
+        return K.to_cl(x, dtype, swap)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.from_cl(g.contiguous(), ctx.channels, ctx.swap), None, None
+
+
+class FromChannelsLast(Function):
+    @staticmethod
+    def forward(ctx, t, channels, swap):
+        ctx.dtype, ctx.swap = t.dtype, swap
+        return K.from_cl(t, channels, swap)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.to_cl(g.contiguous(), ctx.dtype, ctx.swap), None, None
+
+
+# ------------------------------------------------------------------ convolution
+class ConvSpec:
+    """Static description + per-forward state of one convolution call."""
+
+    def __init__(self, ksize, cout, cin, *, act=L.ACT_NONE, up2=False, relu_in=False, sn=None):
+        self.ksize, self.cout, self.cin = tuple(ksize), cout, cin
+        self.act, self.up2, self.relu_in = act, up2, relu_in
+        self.sn = sn            # (u, v) parameter tensors of a spectral-norm wrapper, or None
+        self.sigma = None       # set per forward
+        self.pack = None
+
+
+class Conv(Function):
+    """y = act(conv(x; w / sigma) + b [+ res])        (spec.pack is filled by the caller)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, spec):
+        pk = spec.pack
+        y = K.conv_forward(x, pk.wf, spec.ksize, spec.cout, bias=b, res=res, act=spec.act, up2=spec.up2,
+                           relu_in=spec.relu_in)
+        ctx.spec, ctx.pk, ctx.sigma = spec, pk, spec.sigma
+        ctx.has_res = res is not None
+        ctx.save_for_backward(x, w, y if spec.act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        spec, pk = ctx.spec, ctx.pk
+        dy = dy.contiguous()
+        if spec.act != L.ACT_NONE:
+            dy = K.act_backward(dy, y, spec.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if spec.up2:
+                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip)
+                dx = K.pool(dx, 1, scale=1.0)                 # transpose of nearest x2
+                if spec.relu_in:
+                    dx = K.act_backward(dx, x, L.ACT_RELU)
+            else:
+                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None)
+        if ctx.needs_input_grad[1]:
+            G = torch.zeros_like(w)
+            K.conv_wgrad(x, dy, G, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in)
+            if spec.sn is not None:
+                u, v = spec.sn            # CURRENT u / v on purpose (reference quirk 7)
+                dw = K.sn_backward(G, w, u, v, ctx.sigma)
+            else:
+                dw = G
+        if ctx.needs_input_grad[2]:
+            db = K.colsum(dy, spec.cout)
+        return dx, dw, db, (dy if ctx.has_res else None), None
+
+
+class Pool(Function):
+    """average pool over (pt,2,2)"""
+
+    @staticmethod
+    def forward(ctx, x, pt):
+        ctx.pt = pt
+        return K.pool(x, pt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.unpool(g.contiguous(), ctx.pt), None
+
+
+# ------------------------------------------------------------------ fp32 linear / embedding
+class LinearF32(Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return K.linear_forward(x.contiguous(), W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        din, dW, db = K.linear_backward(g.contiguous(), x.contiguous(), W, ctx.needs_input_grad[0],
+                                        ctx.needs_input_grad[1], ctx.has_bias)
+        return din, dW, db
+
+
+class Embedding(Function):
+    @staticmethod
+    def forward(ctx, W, idx32):
+        ctx.save_for_backward(idx32)
+        ctx.rows = W.shape[0]
+        return K.row_copy(W, idx32, idx32.numel(), W.shape[1], scatter=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx32,) = ctx.saved_tensors
+        return K.embedding_backward(g.contiguous(), idx32, ctx.rows), None
+
+
+# ------------------------------------------------------------------ conditional batch norm (+ReLU)
+class CondBatchNorm(Function):
+    """y = relu?(gb[s][:C] * bn(x) + gb[s][C:]),  s = samp[frame]     Normalization.py:78-88"""
+
+    @staticmethod
+    def forward(ctx, x, gb, samp, C_real, relu, training, run_mean, run_var, eps, momentum):
+        mean, rstd = K.bn_stats(x, C_real, training, eps, momentum, run_mean, run_var)
+        y = K.cbn_apply(x, C_real, mean, rstd, gb, samp, relu)
+        ctx.save_for_backward(x, y, gb, samp, mean, rstd)
+        ctx.C_real, ctx.relu, ctx.training = C_real, relu, training
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, gb, samp, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("CondBatchNorm backward is implemented for training mode only")
+        dx, dgb = K.cbn_backward(g.contiguous(), y, x, ctx.C_real, mean, rstd, gb, samp, ctx.relu)
+        return dx, dgb, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------ ConvGRU layer
+class ConvGRULayer(Function):
+    """All T steps of one ConvGRUCell (ConvGRU.py:29-54).  x: [T*B,S,S,Cin_p] t-major frames, or
+    [B,S,S,Cin_p] when the same input feeds every step (first GRU of the generator).
+    Returns h for every step as [T*B,S,S,hidden]."""
+
+    @staticmethod
+    def forward(ctx, x, wu, bu, wr, br, wo, bo, T, shared_x, h0):
+        dev, dtype = x.device, x.dtype
+        hid, ctot, k = wu.shape[0], wu.shape[1], wu.shape[-1]
+        cin = ctot - hid
+        B = x.shape[0] if shared_x else x.shape[0] // T
+        S1, S2 = x.shape[1], x.shape[2]
+        M = B * S1 * S2
+        px = K.PackedConv(dtype, 3 * hid, cin, (k, k), dev)
+        pur = K.PackedConv(dtype, 2 * hid, hid, (k, k), dev)
+        po = K.PackedConv(dtype, hid, hid, (k, k), dev)
+        for g, w in enumerate((wu, wr, wo)):
+            px.fill(w, co_off=g * hid, ci_off=0)
+        pur.fill(wu, co_off=0, ci_off=cin).fill(wr, co_off=hid, ci_off=cin)
+        po.fill(wo, ci_off=cin)
+        bias3 = torch.cat([bu, br, bo])
+        gx = K.conv_forward(x, px.wf, (k, k), 3 * hid, bias=bias3)
+        mk = lambda: torch.empty(T, B, S1, S2, hid, dtype=dtype, device=dev)
+        h_all, u_all, r_all, o_all, hr_all = mk(), mk(), mk(), mk(), mk()
+        h32 = torch.empty(2, M, hid, dtype=torch.float32, device=dev) if dtype != torch.float32 else None
+        lib = L.lib()
+        ntaps = k * k
+        ns1 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), 2 * hid, hid, ntaps)
+        ns2 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, hid, ntaps)
+        ns3 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, 2 * hid, ntaps)
+        ws = torch.empty(max(ns1 * 2, ns2, ns3) * M * hid, dtype=torch.float32, device=dev)
+        d = L.GruDesc()
+        d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.dt(x), T, B, S1, S2, hid, k
+        d.gx_stride = 0 if shared_x else M * 3 * hid
+        d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
+        d.h0 = h0.data_ptr() if h0 is not None else None
+        d.h_all, d.u_all, d.r_all = h_all.data_ptr(), u_all.data_ptr(), r_all.data_ptr()
+        d.o_all, d.hr_all = o_all.data_ptr(), hr_all.data_ptr()
+        d.h32 = h32.data_ptr() if h32 is not None else None
+        d.ws = ws.data_ptr()
+        L.check(lib.dvd_convgru_layer_forward(C.byref(d), L.stream()))
+        ctx.save_for_backward(x, wu, wr, wo, h_all, u_all, r_all, o_all, hr_all, h0)
+        ctx.packs = (px, pur, po)
+        ctx.meta = (T, B, S1, S2, hid, cin, k, shared_x, ws.numel())
+        return h_all.view(T * B, S1, S2, hid)
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, wu, wr, wo, h_all, u_all, r_all, o_all, hr_all, h0 = ctx.saved_tensors
+        px, pur, po = ctx.packs
+        T, B, S1, S2, hid, cin, k, shared_x, ws_n = ctx.meta
+        dev, dtype = x.device, x.dtype
+        M = B * S1 * S2
+        dh = dh.contiguous()
+        dg = torch.empty(T * B, S1, S2, 3 * hid, dtype=dtype, device=dev)
+        carry = torch.empty(M, hid, dtype=torch.float32, device=dev)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+        d = L.GruDesc()
+        d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.dt(x), T, B, S1, S2, hid, k
+        d.wd_ur, d.wd_o = pur.wd.data_ptr(), po.wd.data_ptr()
+        d.h0 = h0.data_ptr() if h0 is not None else None
+        d.h_all, d.u_all, d.r_all = h_all.data_ptr(), u_all.data_ptr(), r_all.data_ptr()
+        d.o_all, d.hr_all = o_all.data_ptr(), hr_all.data_ptr()
+        d.ws, d.dh_out, d.dg, d.carry = ws.data_ptr(), dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
+        L.check(L.lib().dvd_convgru_layer_backward(C.byref(d), L.stream()))
+        # ---- everything below is batched over all T steps ----
+        dgx = K.sum_leading(dg.view(T, -1)).view(B, S1, S2, 3 * hid) if shared_x else dg
+        dx = K.conv_forward(dgx, px.wd, (k, k), px.cip) if ctx.needs_input_grad[0] else None
+        grads = []
+        ctot = cin + hid
+        hflat = h_all.view(T * B, S1, S2, hid)
+        hrflat = hr_all.view(T * B, S1, S2, hid)
+        for g, w in enumerate((wu, wr, wo)):
+            dw = torch.zeros_like(w)
+            K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot)
+            if h0 is not None:
+                raise RuntimeError("gradient through a supplied initial hidden state is not implemented")
+            if T > 1:
+                # h-part: steps 1..T-1 read h_{t-1} (update/reset) or h_{t-1}*r_t (out gate)
+                if g < 2:
+                    K.conv_wgrad(hflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
+                                 frames=(T - 1) * B, x_row0=0, dy_row0=B)
+                else:
+                    K.conv_wgrad(hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
+                                 frames=(T - 1) * B, x_row0=B, dy_row0=B)
+            grads.append(dw)
+        db3 = K.colsum(dg, 3 * hid)
+        return (dx, grads[0], db3[:hid].clone(), grads[1], db3[hid:2 * hid].clone(), grads[2], db3[2 * hid:].clone(),
+                None, None, None)
+
+
+# ------------------------------------------------------------------ attention / head / loss
+class SelfAttention2d(Function):
+    """y = gamma * softmax(q^T k) v + x      Discriminators.py:100-119; qkv from one fused 1x1 conv."""
+
+    @staticmethod
+    def forward(ctx, x, qkv, gamma, dq, C_real):
+        F_ = x.shape[0]
+        N = x.shape[1] * x.shape[2]
+        koff = K.pad8(dq)
+        voff = 2 * koff
+        y = torch.zeros_like(x) if x.shape[-1] != C_real else torch.empty_like(x)
+        att = torch.zeros_like(x)
+        A = torch.empty(F_, N, N, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dvd_attention_forward(L.dt(x), L.ptr(qkv), qkv.shape[-1], dq, koff, voff, L.ptr(x), x.shape[-1],
+                                              C_real, L.ptr(gamma), L.ptr(y), L.ptr(att), L.ptr(A), C.c_longlong(F_), N,
+                                              L.stream()))
+        ctx.save_for_backward(qkv, gamma, att, A)
+        ctx.meta = (dq, C_real, koff, voff, N)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qkv, gamma, att, A = ctx.saved_tensors
+        dq, C_real, koff, voff, N = ctx.meta
+        dy = dy.contiguous()
+        F_ = dy.shape[0]
+        dqkv = torch.zeros_like(qkv)
+        dS = torch.empty_like(A)
+        dgamma = torch.zeros(1, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().dvd_attention_backward(L.dt(dy), L.ptr(qkv), qkv.shape[-1], dq, koff, voff, L.ptr(dy),
+                                               dy.shape[-1], C_real, L.ptr(gamma), L.ptr(att), L.ptr(A), L.ptr(dS),
+                                               L.ptr(dqkv), L.ptr(dgamma), C.c_longlong(F_), N, L.stream()))
+        return dy, dqkv, dgamma, None, None
+
+
+class ProjectionHead(Function):
+    """out[f] = b + sum_c h[f][c] * (w_lin[c]/s_l + embed[cls[f]][c]/s_e),  h = sum_p relu(feat)
+    Discriminators.py:264-291 / 421-447 (both SN wrappers have their own sigma)."""
+
+    @staticmethod
+    def forward(ctx, feat, w_lin, b_lin, w_emb, cls32, sn_lin, sn_emb, C_real):
+        F_ = feat.shape[0]
+        P = feat.numel() // (F_ * feat.shape[-1])
+        lib = L.lib()
+        hsum = torch.empty(F_, C_real, dtype=torch.float32, device=feat.device)
+        L.check(lib.dvd_relu_spatial_sum(L.dt(feat), L.ptr(feat), L.ptr(hsum), C.c_longlong(F_), P, C_real,
+                                         feat.shape[-1], L.stream()))
+        s_l = K.sn_power_iter(w_lin, *sn_lin)
+        s_e = K.sn_power_iter(w_emb, *sn_emb)
+        out = torch.empty(F_, dtype=torch.float32, device=feat.device)
+        L.check(lib.dvd_proj_head_forward(L.ptr(hsum), L.ptr(w_lin), L.ptr(s_l), L.ptr(b_lin), L.ptr(w_emb), L.ptr(s_e),
+                                          L.ptr(cls32), L.ptr(out), C.c_longlong(F_), C_real, L.stream()))
+        ctx.save_for_backward(feat, hsum, w_lin, w_emb, cls32, s_l, s_e)
+        ctx.sn = (sn_lin, sn_emb)
+        ctx.meta = (F_, P, C_real)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, hsum, w_lin, w_emb, cls32, s_l, s_e = ctx.saved_tensors
+        F_, P, C_real = ctx.meta
+        sn_lin, sn_emb = ctx.sn
+        lib = L.lib()
+        dout = dout.contiguous()
+        need_w = ctx.needs_input_grad[1]
+        dh = torch.empty_like(hsum)
+        g_lin = torch.zeros_like(w_lin) if need_w else None
+        g_emb = torch.zeros_like(w_emb) if need_w else None
+        g_b = torch.zeros(1, dtype=torch.float32, device=feat.device) if need_w else None
+        L.check(lib.dvd_proj_head_backward(L.ptr(dout), L.ptr(hsum), L.ptr(w_lin), L.ptr(s_l), L.ptr(w_emb), L.ptr(s_e),
+                                           L.ptr(cls32), L.ptr(dh), L.ptr(g_lin), L.ptr(g_emb), L.ptr(g_b),
+                                           C.c_longlong(F_), C_real, L.stream()))
+        dfeat = None
+        if ctx.needs_input_grad[0]:
+            dfeat = torch.empty_like(feat)
+            L.check(lib.dvd_relu_spatial_sum_backward(L.dt(feat), L.ptr(dh), L.ptr(feat), L.ptr(dfeat), C.c_longlong(F_),
+                                                      P, C_real, feat.shape[-1], L.stream()))
+        dwl = dwe = None
+        if need_w:
+            dwl = K.sn_backward(g_lin, w_lin, sn_lin[0], sn_lin[1], s_l)
+            dwe = K.sn_backward(g_emb, w_emb, sn_emb[0], sn_emb[1], s_e)
+        return dfeat, dwl, g_b, dwe, None, None, None, None
+
+
+class AdvLoss(Function):
+    """Trainer.calc_loss, trainer.py:114-121 -> scalar"""
+
+    @staticmethod
+    def forward(ctx, out, real_flag, hinge):
+        out = out.contiguous()
+        loss = torch.zeros(1, dtype=torch.float32, device=out.device)
+        dout = torch.empty_like(out)
+        L.check(L.lib().dvd_adv_loss(L.ptr(out), C.c_longlong(out.numel()), int(hinge), int(real_flag), L.ptr(loss),
+                                     L.ptr(dout), C.c_float(1.0), L.stream()))
+        ctx.save_for_backward(dout)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dout,) = ctx.saved_tensors
+        return dout * g, None, None
+
+
+# ------------------------------------------------------------------ reference-layout helpers
+class VidDownsample(Function):
+    """utils.py:77-83"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return K.vid_downsample_raw(x.contiguous(), False, ctx.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.vid_downsample_raw(g.contiguous(), True, ctx.shape)
+
+
+class GatherFrames(Function):
+    """data[:, ids] for [B, T, ...] fp32 data (utils.py:63)"""
+
+    @staticmethod
+    def forward(ctx, x, ids):
+        B, T = x.shape[:2]
+        k = ids.numel()
+        rows = (torch.arange(B, device=x.device).view(B, 1) * T + ids.view(1, k).to(x.device)).reshape(-1).int()
+        Lr = x[0, 0].numel()
+        ctx.save_for_backward(rows)
+        ctx.shape = tuple(x.shape)
+        out = K.row_copy(x.contiguous().view(B * T, Lr), rows, B * k, Lr, scatter=False)
+        return out.view(B, k, *x.shape[2:])
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        B, T = ctx.shape[:2]
+        Lr = g[0, 0].numel()
+        out = K.row_copy(g.contiguous().view(-1, Lr), rows, B * T, Lr, scatter=True)
+        return out.view(ctx.shape), None

@@ -1,0 +1,131 @@
+"""Generator of DVD-GAN on the HIP kernels -- same constructor / forward signature, same
+state_dict keys and the same results (incl. quirks) as Module/Generator.py:13-120,
+Module/ConvGRU.py and Module/GResBlock.py, but organised for the hardware:
+
+  * frames are kept t-major ([T][B][H][W][C], channels-last) through the whole network, so every
+    time step of a ConvGRU is one contiguous GEMM operand and no permute/stack/cat is ever run;
+  * each ConvGRU is evaluated layer by layer: the x-half of all gate convolutions is one batched
+    convolution over all T steps, only the h-half stays on the serial chain (csrc/gru.hip);
+  * the reference's condition mis-ordering (Generator.py:103-110) becomes an index table `samp`.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import kern as K
+from . import lib as L
+from .sn_layers import ConditionalNorm, ConvParams, SpectralNormConv
+
+
+class ConvGRUCell(nn.Module):
+    """Parameter holder with the reference keys {reset,update,out}_gate.{weight,bias} (ConvGRU.py:16-26)."""
+
+    def __init__(self, input_size, hidden_size, kernel_size):
+        super().__init__()
+        self.input_size, self.hidden_size, self.kernel_size = input_size, hidden_size, kernel_size
+        k = (kernel_size, kernel_size)
+        self.reset_gate = ConvParams(input_size + hidden_size, hidden_size, k, "orthogonal")
+        self.update_gate = ConvParams(input_size + hidden_size, hidden_size, k, "orthogonal")
+        self.out_gate = ConvParams(input_size + hidden_size, hidden_size, k, "orthogonal")
+
+    def run(self, x, T, shared_x, h0=None):
+        return Fn.ConvGRULayer.apply(x, self.update_gate.weight, self.update_gate.bias, self.reset_gate.weight,
+                                     self.reset_gate.bias, self.out_gate.weight, self.out_gate.bias, T, shared_x, h0)
+
+
+class ConvGRU(nn.Module):
+    """ConvGRU.py:57-133.  `run` processes ALL T steps: layer l over the whole sequence, then layer
+    l+1 (identical data flow: layer l at step t needs layer l-1 at step t and itself at t-1)."""
+
+    def __init__(self, input_size, hidden_sizes, kernel_sizes, n_layers):
+        super().__init__()
+        if not isinstance(hidden_sizes, list):
+            hidden_sizes = [hidden_sizes] * n_layers
+        if not isinstance(kernel_sizes, list):
+            kernel_sizes = [kernel_sizes] * n_layers
+        assert len(hidden_sizes) == n_layers, "`hidden_sizes` must have the same length as n_layers"
+        assert len(kernel_sizes) == n_layers, "`kernel_sizes` must have the same length as n_layers"
+        self.input_size, self.hidden_sizes, self.kernel_sizes, self.n_layers = input_size, hidden_sizes, kernel_sizes, n_layers
+        self.cells = nn.ModuleList(
+            ConvGRUCell(input_size if i == 0 else hidden_sizes[i - 1], hidden_sizes[i], kernel_sizes[i])
+            for i in range(n_layers))
+
+    def run(self, x, T, shared_x, hidden=None):
+        """x: [T*B,S,S,C] t-major (or [B,S,S,C] if shared_x).  Returns the list of per-layer
+        sequences [T*B,S,S,h_l] (the reference returns the last step's list per call)."""
+        outs = []
+        for i, cell in enumerate(self.cells):
+            x = cell.run(x, T, shared_x and i == 0, None if hidden is None else hidden[i])
+            outs.append(x)
+        return outs
+
+
+class GResBlock(nn.Module):
+    """GResBlock.py:9-86 with bn=True, downsample_factor=1 (the only configuration the generator uses)."""
+
+    def __init__(self, in_channel, out_channel, n_class=96, upsample_factor=2):
+        super().__init__()
+        self.upsample_factor = upsample_factor
+        self.conv0 = SpectralNormConv(in_channel, out_channel, (3, 3))
+        self.conv1 = SpectralNormConv(out_channel, out_channel, (3, 3))
+        self.conv_sc = SpectralNormConv(in_channel, out_channel, (1, 1))
+        self.CBNorm1 = ConditionalNorm(in_channel, n_class)
+        self.CBNorm2 = ConditionalNorm(out_channel, n_class)
+
+    def run(self, x, cond, samp):
+        up = self.upsample_factor != 1
+        a1 = self.CBNorm1(x, cond, samp, relu=True)
+        c0 = self.conv0(a1, up2=up)
+        a2 = self.CBNorm2(c0, cond, samp, relu=True)
+        skip = self.conv_sc(x, up2=up)
+        return self.conv1(a2, res=skip)
+
+
+class Generator(nn.Module):
+    """Generator(in_dim=120, latent_dim=4, n_class=4, ch=32, n_frames=48, hierar_flag=False)
+    .forward(z [B,in_dim] f32, class_id [B] i64) -> [B, T, 3, 16*latent_dim, 16*latent_dim] f32."""
+
+    def __init__(self, in_dim=120, latent_dim=4, n_class=4, ch=32, n_frames=48, hierar_flag=False,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        if hierar_flag:
+            raise NotImplementedError("hierar_flag=True is broken in the reference (Generator.py:66,109)")
+        self.in_dim, self.latent_dim, self.n_class, self.ch, self.n_frames = in_dim, latent_dim, n_class, ch, n_frames
+        self.hierar_flag = hierar_flag
+        self.compute_dtype = compute_dtype
+        self.embedding = nn.Embedding(n_class, in_dim)
+        self.affine_transfrom = nn.Linear(in_dim * 2, latent_dim * latent_dim * 8 * ch)
+        c8, c4, c2 = 8 * ch, 4 * ch, 2 * ch
+        nc = in_dim * 2
+        self.conv = nn.ModuleList([
+            ConvGRU(c8, [c8, 2 * c8, c8], [3, 5, 3], 3),
+            GResBlock(c8, c8, nc, 1), GResBlock(c8, c8, nc),
+            ConvGRU(c8, [c8, 2 * c8, c8], [3, 5, 3], 3),
+            GResBlock(c8, c8, nc, 1), GResBlock(c8, c8, nc),
+            ConvGRU(c8, [c8, 2 * c8, c8], [3, 5, 3], 3),
+            GResBlock(c8, c8, nc, 1), GResBlock(c8, c4, nc),
+            ConvGRU(c4, [c4, 2 * c4, c4], [3, 5, 5], 3),
+            GResBlock(c4, c4, nc, 1), GResBlock(c4, c2, nc),
+        ])
+        self.colorize = SpectralNormConv(c2, 3, (3, 3))
+
+    def forward(self, x, class_id):
+        B, T = x.shape[0], self.n_frames
+        dev = x.device
+        class_emb = Fn.Embedding.apply(self.embedding.weight, class_id.to(torch.int32))
+        zc = torch.cat([x, class_emb], 1)
+        y = Fn.LinearF32.apply(zc, self.affine_transfrom.weight, self.affine_transfrom.bias)
+        y = y.view(B, 8 * self.ch, self.latent_dim, self.latent_dim)
+        y = Fn.ToChannelsLast.apply(y, self.compute_dtype, None)
+        # frame (t,b) is stored at t*B+b; the reference conditions frame b*T+t on row (b*T+t) mod B
+        t_idx = torch.arange(T, device=dev).view(T, 1)
+        b_idx = torch.arange(B, device=dev).view(1, B)
+        samp = ((b_idx * T + t_idx) % B).reshape(-1).to(torch.int32)
+        for k, m in enumerate(self.conv):
+            if isinstance(m, ConvGRU):
+                y = m.run(y, T, shared_x=(k == 0))[-1]
+            else:
+                y = m.run(y, zc, samp)
+        y = self.colorize(y, relu_in=True, act=L.ACT_TANH)
+        out = Fn.FromChannelsLast.apply(y, 3, (B, T))          # t-major frames -> b-major [B*T,3,H,W]
+        return out.view(B, T, 3, out.shape[-2], out.shape[-1])

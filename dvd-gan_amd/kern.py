@@ -67,12 +67,14 @@ class PackedConv:
         self.wf = torch.zeros(self.ntaps, cout_tot, self.cip, dtype=dtype, device=device)
         self.wd = torch.zeros(self.ntaps, self.cip, self.cop, dtype=dtype, device=device) if need_dgrad else None
 
-    def fill(self, w, sigma=None, co_off=0):
-        """w: fp32 master [Cout_part, Cin, *k]; sigma: device scalar tensor or None."""
-        w = w.contiguous()
+    def fill(self, w, sigma=None, co_off=0, ci_off=0):
+        """w: fp32 master [Cout_part, Cin_tot, *k] of which input channels [ci_off, ci_off+cin) are
+        packed as output rows [co_off, co_off+Cout_part); sigma: device scalar tensor or None."""
+        assert w.is_contiguous() and w.dtype == torch.float32
         L.check(L.lib().dvd_pack_conv_weight(
             L.dt(self.wf), L.ptr(w), L.ptr(sigma), w.shape[0], self.cin, self.ntaps, self.cip, co_off,
-            self.cout, self.cop, L.ptr(self.wf), L.ptr(self.wd), self.k[0], self.k[1], self.k[2], L.stream()))
+            self.cout, self.cop, L.ptr(self.wf), L.ptr(self.wd), self.k[0], self.k[1], self.k[2],
+            ci_off, w.shape[1], L.stream()))
         return self
 
 
@@ -129,18 +131,194 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
     return out
 
 
-def conv_wgrad(x, dy, dw, ksize, cout, cin_real, *, up2=False, relu_in=False, msplit=0):
-    """dw (fp32, reference layout [cout][cin_real][*k], accumulated atomically) += x (*) dy."""
+def conv_wgrad(x, dy, dw, ksize, cout, cin_real, *, up2=False, relu_in=False, msplit=0, dy_col=0,
+               dw_ci_off=0, dw_ci_tot=None, frames=None, x_row0=0, dy_row0=0):
+    """dw[co][dw_ci_off + ci][*k] += sum_rows dy[row][dy_col + co] * x[shifted row][ci]   (fp32 atomics)
+    dw: fp32 master-layout tensor [cout][dw_ci_tot][*k].  x / dy may be row-sliced views given by
+    (tensor, first frame): `frames` frames starting at frame x_row0 of x and dy_row0 of dy."""
     k = _ksize3(ksize)
     F_, T, H, W = _grid(x, ksize, up2)
+    if frames is not None:
+        F_ = frames
     ntaps = k[0] * k[1] * k[2]
+    esz = x.element_size()
+    ci_tot = dw_ci_tot if dw_ci_tot is not None else cin_real
     d = L.WgradDesc()
     d.dtype, d.frames, d.T, d.H, d.W = L.dt(x), F_, T, H, W
     d.C, d.ldx, d.Cin_real = x.shape[-1], x.shape[-1], cin_real
-    d.Cout, d.Cy, d.ldy = cout, dy.shape[-1], dy.shape[-1]
+    cy = min(pad8(cout), dy.shape[-1] - dy_col)
+    d.Cout, d.Cy, d.ldy = cout, cy, dy.shape[-1]
     d.kt, d.kh, d.kw = k
     d.up2, d.relu_in, d.msplit = int(up2), int(relu_in), msplit
-    d.s_co, d.s_ci, d.s_tap = cin_real * ntaps, ntaps, 1
-    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+    d.s_co, d.s_ci, d.s_tap = ci_tot * ntaps, ntaps, 1
+    rows_in = T * (H // 2 if up2 else H) * (W // 2 if up2 else W)
+    d.x = x.data_ptr() + x_row0 * rows_in * x.shape[-1] * esz
+    d.dy = dy.data_ptr() + (dy_row0 * T * H * W * dy.shape[-1] + dy_col) * esz
+    d.dw = dw.data_ptr() + dw_ci_off * ntaps * 4
     L.check(L.lib().dvd_conv_wgrad(C.byref(d), L.stream()))
     return dw
+
+
+# ------------------------------------------------------------------ pointwise wrappers
+def _ll(v):
+    return C.c_longlong(int(v))
+
+
+def _f(v):
+    return C.c_float(float(v))
+
+
+def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var):
+    """-> (mean, rstd) fp32 [C_real]; updates the running buffers in training mode."""
+    ld = x.shape[-1]
+    rows = x.numel() // ld
+    mean = torch.empty(C_real, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    sums = None
+    if training:
+        sums = torch.zeros(2 * C_real, dtype=torch.float64, device=x.device)
+        L.check(L.lib().dvd_bn_stats(L.dt(x), L.ptr(x), _ll(rows), C_real, ld, L.ptr(sums), L.stream()))
+    L.check(L.lib().dvd_bn_finalize(L.ptr(sums), _ll(rows), C_real, _f(eps), _f(momentum), int(training),
+                                    L.ptr(mean), L.ptr(rstd), L.ptr(run_mean), L.ptr(run_var), L.stream()))
+    return mean, rstd
+
+
+def cbn_apply(x, C_real, mean, rstd, gb, samp, relu):
+    y = torch.empty_like(x)
+    frames = x.shape[0]
+    P = x.numel() // (frames * x.shape[-1])
+    L.check(L.lib().dvd_cbn_apply(L.dt(x), L.ptr(x), L.ptr(y), _ll(frames), P, C_real, x.shape[-1], L.ptr(mean),
+                                  L.ptr(rstd), L.ptr(gb), L.ptr(samp), int(relu), L.stream()))
+    return y
+
+
+def cbn_backward(g, a, x, C_real, mean, rstd, gb, samp, relu):
+    """-> (dx, dgb[B][2C])"""
+    dx = torch.empty_like(x)
+    frames = x.shape[0]
+    P = x.numel() // (frames * x.shape[-1])
+    B = gb.shape[0]
+    dgb = torch.zeros_like(gb)
+    s12 = torch.empty(2 * C_real, dtype=torch.float32, device=x.device)
+    L.check(L.lib().dvd_cbn_backward(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
+                                     x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb),
+                                     L.ptr(s12), int(relu), L.stream()))
+    return dx, dgb
+
+
+def _grid4(x):
+    if x.dim() == 5:
+        return x.shape[0], x.shape[1], x.shape[2], x.shape[3]
+    return x.shape[0], 1, x.shape[1], x.shape[2]
+
+
+def pool(x, pt=1, scale=None):
+    """(pt,2,2) window sum * scale (default: average)."""
+    F_, T, H, W = _grid4(x)
+    To, Ho, Wo = T // pt, H // 2, W // 2
+    scale = (1.0 / (4 * pt)) if scale is None else scale
+    shape = (F_, To, Ho, Wo, x.shape[-1]) if x.dim() == 5 else (F_, Ho, Wo, x.shape[-1])
+    y = torch.empty(shape, dtype=x.dtype, device=x.device)
+    L.check(L.lib().dvd_pool(L.dt(x), L.ptr(x), L.ptr(y), _ll(F_), To, Ho, Wo, x.shape[-1], pt, _f(scale), L.stream()))
+    return y
+
+
+def unpool(x, pt=1, scale=None):
+    """nearest replication to (T*pt, 2H, 2W) times scale (default 1/(4*pt): gradient of avg-pool)."""
+    F_, T, H, W = _grid4(x)
+    To, Ho, Wo = T * pt, H * 2, W * 2
+    scale = (1.0 / (4 * pt)) if scale is None else scale
+    shape = (F_, To, Ho, Wo, x.shape[-1]) if x.dim() == 5 else (F_, Ho, Wo, x.shape[-1])
+    y = torch.empty(shape, dtype=x.dtype, device=x.device)
+    L.check(L.lib().dvd_unpool(L.dt(x), L.ptr(x), L.ptr(y), _ll(F_), To, Ho, Wo, x.shape[-1], pt, _f(scale), L.stream()))
+    return y
+
+
+def colsum(x, C_real, out=None):
+    ld = x.shape[-1]
+    if out is None:
+        out = torch.zeros(C_real, dtype=torch.float32, device=x.device)
+    L.check(L.lib().dvd_colsum(L.dt(x), L.ptr(x), _ll(x.numel() // ld), C_real, ld, L.ptr(out), L.stream()))
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    L.check(L.lib().dvd_add(L.dt(a), L.ptr(a), L.ptr(b), L.ptr(out), _ll(a.numel()), L.stream()))
+    return out
+
+
+def sum_leading(x):
+    out = torch.empty(x.shape[1:], dtype=x.dtype, device=x.device)
+    L.check(L.lib().dvd_sum_leading(L.dt(x), L.ptr(x), L.ptr(out), x.shape[0], _ll(out.numel()), L.stream()))
+    return out
+
+
+def act_backward(dy, y, act):
+    dx = torch.empty_like(dy)
+    L.check(L.lib().dvd_act_backward(L.dt(dy), L.ptr(dy), L.ptr(y), L.ptr(dx), _ll(dy.numel()), act, L.stream()))
+    return dx
+
+
+def vid_downsample_raw(src, backward, shape_fwd_in):
+    B, T, Cc, H, W = shape_fwd_in
+    out = torch.empty((B, T, Cc, H, W) if backward else (B, Cc, T, H // 2, W // 2), dtype=torch.float32,
+                      device=src.device)
+    L.check(L.lib().dvd_vid_downsample(L.ptr(src), L.ptr(out), B, T, Cc, H, W, int(backward), L.stream()))
+    return out
+
+
+def row_copy(src, idx, nrows_out, L_, scatter, out=None):
+    """gather: out[r] = src[idx[r]] ; scatter: out[idx[r]] = src[r] (out pre-zeroed, nrows_out rows)."""
+    if out is None:
+        out = (torch.zeros if scatter else torch.empty)(nrows_out, L_, dtype=torch.float32, device=src.device)
+    L.check(L.lib().dvd_row_copy(L.ptr(src), L.ptr(out), L.ptr(idx), _ll(idx.numel()), _ll(L_), int(scatter), L.stream()))
+    return out
+
+
+# ------------------------------------------------------------------ spectral norm / small fp32 layers
+def sn_power_iter(w_bar, u, v):
+    """In-place u, v update; returns a fresh 1-element sigma tensor."""
+    sigma = torch.empty(1, dtype=torch.float32, device=w_bar.device)
+    h = w_bar.shape[0]
+    L.check(L.lib().dvd_sn_power_iter(L.ptr(w_bar), h, w_bar.numel() // h, L.ptr(u), L.ptr(v), L.ptr(sigma), L.stream()))
+    return sigma
+
+
+def sn_backward(G, w_bar, u, v, sigma):
+    dW = torch.zeros_like(w_bar)
+    scratch = torch.empty(1, dtype=torch.float32, device=w_bar.device)
+    h = w_bar.shape[0]
+    L.check(L.lib().dvd_sn_backward(L.ptr(G), L.ptr(w_bar), L.ptr(u), L.ptr(v), L.ptr(sigma), h, w_bar.numel() // h,
+                                    L.ptr(dW), L.ptr(scratch), L.stream()))
+    return dW
+
+
+def linear_forward(inp, W, bias):
+    B, K = inp.shape
+    J = W.shape[0]
+    out = torch.empty(B, J, dtype=torch.float32, device=inp.device)
+    L.check(L.lib().dvd_linear_forward(L.ptr(inp), L.ptr(W), L.ptr(bias), L.ptr(out), B, K, J, L.stream()))
+    return out
+
+
+def linear_backward(dout, inp, W, need_in, need_w, has_bias):
+    B, K = inp.shape
+    J = W.shape[0]
+    din = torch.empty_like(inp) if need_in else None
+    dW = torch.zeros_like(W) if need_w else None
+    db = torch.zeros(J, dtype=torch.float32, device=inp.device) if (need_w and has_bias) else None
+    L.check(L.lib().dvd_linear_backward(L.ptr(dout), L.ptr(inp), L.ptr(W), L.ptr(din), 0, L.ptr(dW), L.ptr(db), B, K, J,
+                                        L.stream()))
+    return din, dW, db
+
+
+def embedding_backward(dout, idx, nrows):
+    dW = torch.zeros(nrows, dout.shape[1], dtype=torch.float32, device=dout.device)
+    L.check(L.lib().dvd_embedding_backward(L.ptr(dout), L.ptr(idx), L.ptr(dW), _ll(dout.shape[0]), dout.shape[1], L.stream()))
+    return dW
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step):
+    L.check(L.lib().dvd_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), _ll(p.numel()), _f(lr), _f(b1), _f(b2),
+                                  _f(eps), int(step), L.stream()))

@@ -70,3 +70,13 @@ def ptr(t):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class GruDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("hidden", C.c_int), ("k", C.c_int), ("gx_stride", C.c_longlong),
+                ("gx", C.c_void_p), ("w_ur", C.c_void_p), ("w_o", C.c_void_p), ("wd_ur", C.c_void_p),
+                ("wd_o", C.c_void_p), ("h0", C.c_void_p),
+                ("h_all", C.c_void_p), ("u_all", C.c_void_p), ("r_all", C.c_void_p), ("o_all", C.c_void_p),
+                ("hr_all", C.c_void_p), ("h32", C.c_void_p), ("ws", C.c_void_p),
+                ("dh_out", C.c_void_p), ("dg", C.c_void_p), ("carry", C.c_void_p), ("dh0", C.c_void_p)]

@@ -1,0 +1,132 @@
+"""Parameter containers that reproduce the reference state_dict layout, plus the spectral-norm and
+conditional-batch-norm front ends of the HIP kernels.
+
+Reference: Module/Normalization.py (SpectralNorm :10-64, ConditionalNorm :66-88).  Key layout kept:
+  <name>.module.{bias, weight_u, weight_v, weight_bar}        (SpectralNorm wrapper)
+  <name>.{bn.running_mean, bn.running_var, bn.num_batches_tracked, embed.weight, embed.bias}
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import kern as K
+from . import lib as L
+
+
+def _conv_default_init(w, b):
+    """nn.Conv*/nn.Linear default: kaiming_uniform(a=sqrt(5)) and bias U(+-1/sqrt(fan_in))."""
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+    if b is not None:
+        fan_in = w[0].numel()
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        nn.init.uniform_(b, -bound, bound)
+
+
+class ConvParams(nn.Module):
+    """Plain (not spectrally normalised) conv parameters: `.weight`, `.bias` -- nn.Conv2d keys."""
+
+    def __init__(self, cin, cout, ksize, init="default"):
+        super().__init__()
+        self.cin, self.cout, self.ksize = cin, cout, tuple(ksize)
+        self.weight = nn.Parameter(torch.empty(cout, cin, *ksize))
+        self.bias = nn.Parameter(torch.empty(cout))
+        if init == "orthogonal":            # ConvGRU.py:20-26
+            nn.init.orthogonal_(self.weight)
+            nn.init.zeros_(self.bias)
+        elif init == "xavier":              # Discriminators.py:73-76
+            nn.init.xavier_uniform_(self.weight)
+            nn.init.zeros_(self.bias)
+        else:
+            _conv_default_init(self.weight, self.bias)
+
+
+class _SNInner(nn.Module):
+    """What the reference leaves inside SpectralNorm.module after _make_params (:43-59)."""
+
+    def __init__(self, shape, bias_n, init_weight=None):
+        super().__init__()
+        w = torch.empty(*shape)
+        b = torch.empty(bias_n) if bias_n else None
+        if init_weight is not None:
+            init_weight(w)
+            if b is not None:
+                nn.init.uniform_(b, -1 / math.sqrt(w[0].numel()), 1 / math.sqrt(w[0].numel()))
+        else:
+            _conv_default_init(w, b)
+        if b is not None:
+            self.bias = nn.Parameter(b)
+        height = shape[0]
+        width = w.numel() // height
+        u = torch.randn(height)
+        v = torch.randn(width)
+        self.weight_u = nn.Parameter(u / (u.norm() + 1e-12), requires_grad=False)
+        self.weight_v = nn.Parameter(v / (v.norm() + 1e-12), requires_grad=False)
+        self.weight_bar = nn.Parameter(w)
+
+
+class SpectralNormConv(nn.Module):
+    """SpectralNorm(nn.Conv2d / nn.Conv3d).  Every call runs one power iteration (also in eval /
+    no_grad, quirk 2), then packs W_bar / sigma for the MFMA kernels."""
+
+    def __init__(self, cin, cout, ksize):
+        super().__init__()
+        self.cin, self.cout, self.ksize = cin, cout, tuple(ksize)
+        self.module = _SNInner((cout, cin) + self.ksize, cout)
+        self.train_weights = True          # False: treat weights as constants (G step through D)
+
+    def forward(self, x, *, res=None, act=L.ACT_NONE, up2=False, relu_in=False):
+        m = self.module
+        sigma = K.sn_power_iter(m.weight_bar.data, m.weight_u.data, m.weight_v.data)
+        spec = Fn.ConvSpec(self.ksize, self.cout, self.cin, act=act, up2=up2, relu_in=relu_in,
+                           sn=(m.weight_u.data, m.weight_v.data))
+        spec.sigma = sigma
+        spec.pack = K.PackedConv(x.dtype, self.cout, self.cin, self.ksize, x.device).fill(m.weight_bar.data, sigma)
+        w, b = (m.weight_bar, m.bias) if self.train_weights else (m.weight_bar.detach(), m.bias.detach())
+        return Fn.Conv.apply(x, w, b, res, spec)
+
+
+class PlainConv(nn.Module):
+    """nn.Conv2d with reference keys `.weight/.bias` (attention q/k/v)."""
+
+    def __init__(self, cin, cout, ksize, init="default"):
+        super().__init__()
+        self.p = None
+        self.cin, self.cout, self.ksize = cin, cout, tuple(ksize)
+        self.weight = nn.Parameter(torch.empty(cout, cin, *ksize))
+        self.bias = nn.Parameter(torch.empty(cout))
+        if init == "xavier":
+            nn.init.xavier_uniform_(self.weight)
+            nn.init.zeros_(self.bias)
+        else:
+            _conv_default_init(self.weight, self.bias)
+
+
+class ConditionalNorm(nn.Module):
+    """Normalization.py:66-88.  `embed` is an nn.Linear(n_condition, 2*C) with the reference's
+    (axis-confused) init: weight[:, :C] ~ N(1, .02), weight[:, C:] = 0 (quirk, :75-76)."""
+
+    def __init__(self, in_channel, n_condition):
+        super().__init__()
+        self.in_channel = in_channel
+        self.bn = nn.Module()
+        self.bn.register_buffer("running_mean", torch.zeros(in_channel))
+        self.bn.register_buffer("running_var", torch.ones(in_channel))
+        self.bn.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.embed = nn.Module()
+        w = torch.empty(in_channel * 2, n_condition)
+        b = torch.empty(in_channel * 2)
+        _conv_default_init(w, b)
+        w[:, :in_channel].normal_(1, 0.02)
+        w[:, in_channel:].zero_()
+        self.embed.weight = nn.Parameter(w)
+        self.embed.bias = nn.Parameter(b)
+
+    def forward(self, x, cond, samp, relu=True):
+        """x: channels-last [frames, H, W, Cp]; cond: fp32 [B, n_condition]; samp: int32 [frames]."""
+        gb = Fn.LinearF32.apply(cond, self.embed.weight, self.embed.bias)
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return Fn.CondBatchNorm.apply(x, gb, samp, self.in_channel, relu, self.training, self.bn.running_mean,
+                                      self.bn.running_var, 1e-5, 0.1)

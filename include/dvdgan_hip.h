@@ -100,7 +100,9 @@ int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream);
  * (e.g. update|reset|out gates, q|k|v): wf row length stays Cip, wd row length is co_tot. */
 int dvd_pack_conv_weight(int dtype, const float* w, const float* sigma, int Cout, int Cin, int ntaps,
                          int Cip, int co_off, int co_tot_f, int co_tot_d, void* wf, void* wd,
-                         int kt, int kh, int kw, void* stream);
+                         int kt, int kh, int kw, int ci_off, int ci_tot, void* stream);
+/* ci_off/ci_tot: the master tensor is [Cout][ci_tot][ntaps] and only input channels
+ * [ci_off, ci_off+Cin) are packed (x-part / h-part of a ConvGRU gate, ConvGRU.py:16-18). */
 
 /* Layout / dtype conversion at the module boundary (reference tensors are NCHW-style fp32):
  *   to_cl:   src fp32 [F][C][P]  -> dst [F][P][Cp]  (pad channels zero-filled)
@@ -114,6 +116,108 @@ int dvd_from_channels_last(int dtype, const void* src, float* dst, long long F, 
                            int Cp, int A, int B, int swap_ab, void* stream);
 /* dst[i] (+)= (float)src[i] * alpha, n elements; src/dst dtype given separately */
 int dvd_convert(int src_dtype, const void* src, int dst_dtype, void* dst, long long n, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * ConvGRU layer, serial half (Module/ConvGRU.py:29-54 for ONE layer, all T steps; the T loop of
+ * Module/Generator.py:87-97 runs inside the library).  The caller supplies the batched x-path
+ * pre-activations gx[t] = Wx * x_t + b (columns u|r|o, 3*hidden) and receives h_t plus the
+ * tensors BPTT needs.  Backward fills dg[t] = d loss / d pre-activation (u|r|o) for every step;
+ * weight and input gradients are then batched over T with dvd_conv_wgrad / dvd_conv_forward.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int dtype;
+    int T, B, H, W;            /* steps, batch, spatial grid: M = B*H*W rows per step            */
+    int hidden, k;             /* hidden channels (multiple of 8), square kernel size            */
+    long long gx_stride;       /* elements between gx[t] and gx[t+1]; 0 = same gx for every t    */
+    const void* gx;            /* [T|1][M][3*hidden]                                            */
+    const void* w_ur;          /* forward pack  [k*k][2*hidden][hidden]  (update|reset, h-part)  */
+    const void* w_o;           /* forward pack  [k*k][hidden][hidden]    (out gate, h-part)      */
+    const void* wd_ur;         /* backward-data pack [k*k][hidden][2*hidden]                     */
+    const void* wd_o;          /* backward-data pack [k*k][hidden][hidden]                       */
+    const void* h0;            /* optional initial state [M][hidden] (ConvGRU.py:104), or NULL   */
+    void* h_all; void* u_all; void* r_all; void* o_all; void* hr_all;   /* each [T][M][hidden]   */
+    float* h32;                /* optional fp32 carry of h, [2][M][hidden] (bf16 mode), or NULL  */
+    float* ws;                 /* split-K workspace, see dvd_convgru_ws_floats                   */
+    /* backward only */
+    const void* dh_out;        /* [T][M][hidden] gradient wrt every h_t, or NULL                 */
+    void* dg;                  /* out [T][M][3*hidden]                                           */
+    float* carry;              /* scratch [M][hidden] fp32                                       */
+    float* dh0;                /* optional out [M][hidden] fp32: gradient wrt h0                 */
+} dvd_gru_desc;
+int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream);
+int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream);
+int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch norm statistics + conditional batch norm (Module/Normalization.py:78-88; F.batch_norm +
+ * F.linear + mul/add).  `samp[frame]` = row of the condition matrix used by that frame (this
+ * is where the reference's condition mis-ordering, Generator.py:109-110, is expressed).
+ * gb = Linear(cond) as [B][2*C] (gamma | beta), computed with dvd_linear_forward.
+ * ---------------------------------------------------------------------------------------- */
+int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int ld, double* sums /*[2C], zeroed*/, void* stream);
+int dvd_bn_finalize(const double* sums, long long rows, int C, float eps, float momentum, int training,
+                    float* mean, float* rstd, float* run_mean, float* run_var, void* stream);
+int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames, int P, int C, int ld, const float* mean,
+                  const float* rstd, const float* gb, const int* samp, int relu, void* stream);
+/* g: gradient wrt the (ReLU'd) output, a: that output (ReLU mask), x: CBN input.  Produces dx and
+ * accumulates dgb[B][2C] (zeroed by the caller); s12[2C] is scratch. */
+int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames, int P,
+                     int C, int ld, const float* mean, const float* rstd, const float* gb, const int* samp, int B,
+                     float* dgb, float* s12, int relu, void* stream);
+
+/* avg / sum pooling over (pt,2,2) windows and its transpose (nearest replication), channels-last.
+ * F.avg_pool2d / F.avg_pool3d at Discriminators.py:197,206,225,249,352,361,380,408 and the
+ * gradient of F.interpolate(scale_factor=2) (GResBlock.py:55,72). Output grid given. */
+int dvd_pool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt, float scale, void* stream);
+int dvd_unpool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt, float scale, void* stream);
+int dvd_colsum(int dtype, const void* x, long long rows, int C, int ld, float* out /* += */, void* stream);
+int dvd_add(int dtype, const void* a, const void* b, void* out, long long n, void* stream);
+int dvd_sum_leading(int dtype, const void* in /*[L][n]*/, void* out /*[n]*/, int L, long long n, void* stream);
+int dvd_act_backward(int dtype, const void* dy, const void* y, void* dx, long long n, int act, void* stream);
+/* utils.py:77-83 vid_downsample on reference-layout fp32 tensors (+ its backward) and
+ * utils.py:60-63 frame gather: rows of L floats copied by index (scatter = transpose). */
+int dvd_vid_downsample(const float* src, float* dst, int B, int T, int C, int H, int W, int backward, void* stream);
+int dvd_row_copy(const float* src, float* dst, const int* idx, long long nrows, long long L, int scatter, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spectral norm (Module/Normalization.py:19-31: mv, mv, norm, dot, div) and its backward
+ *   dW_bar += G/sigma - (sum G*W_bar)/sigma^2 * u v^T        (u, v: CURRENT buffers, quirk 7)
+ * ---------------------------------------------------------------------------------------- */
+int dvd_sn_power_iter(const float* W, int h, int w, float* u, float* v, float* sigma, void* stream);
+int dvd_sn_backward(const float* G, const float* W, const float* u, const float* v, const float* sigma, int h, int w,
+                    float* dW, float* scratch /*1 float*/, void* stream);
+int dvd_sn_scale(const float* W, const float* sigma, float* out, long long n, void* stream);
+
+/* fp32 nn.Linear (Generator.py:75, Normalization.py:80) and nn.Embedding backward (Generator.py:70) */
+int dvd_linear_forward(const float* in, const float* W, const float* bias, float* out, int B, int K, int J, void* stream);
+int dvd_linear_backward(const float* dout, const float* in, const float* W, float* din, int din_accumulate,
+                        float* dW /* += */, float* dbias /* += */, int B, int K, int J, void* stream);
+int dvd_embedding_backward(const float* dout, const int* idx, float* dW /* += */, long long n, int D, void* stream);
+
+/* Projection head (Discriminators.py:264-291 / 421-447): relu + spatial sum, SN linear + SN embed */
+int dvd_relu_spatial_sum(int dtype, const void* feat, float* hsum, long long F, int P, int C, int ld, void* stream);
+int dvd_relu_spatial_sum_backward(int dtype, const float* dh, const void* feat, void* dfeat, long long F, int P, int C,
+                                  int ld, void* stream);
+int dvd_proj_head_forward(const float* hsum, const float* wl, const float* sl, const float* bias, const float* emb,
+                          const float* se, const int* cls, float* out, long long F, int C, void* stream);
+int dvd_proj_head_backward(const float* dout, const float* hsum, const float* wl, const float* sl, const float* emb,
+                           const float* se, const int* cls, float* dh, float* g_lin, float* g_emb, float* g_bias,
+                           long long F, int C, void* stream);
+
+/* Trainer.calc_loss (trainer.py:114-121): *loss += mean(...), dout = grad_scale * d mean / d out */
+int dvd_adv_loss(const float* out, long long n, int hinge, int real_flag, float* loss, float* dout, float grad_scale,
+                 void* stream);
+/* torch.optim.Adam.step (trainer.py:252,268,306) on one flat fp32 buffer */
+int dvd_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream);
+
+/* 2-D self attention (Discriminators.py:100-119: bmm, softmax, bmm, gamma*out + x) */
+int dvd_attention_forward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* x, int ldx, int C,
+                          const float* gamma, void* y, void* att_out, float* A, long long frames, int N, void* stream);
+int dvd_attention_backward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* dy, int ldx,
+                           int C, const float* gamma, const void* att_out, const float* A, float* dS, void* dqkv,
+                           float* dgamma, long long frames, int N, void* stream);
 
 #ifdef __cplusplus
 }

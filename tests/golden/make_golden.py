@@ -170,8 +170,8 @@ def f4_convgru(R):
     for p in cell.parameters():  # non-zero biases so the bias path is exercised
         if p.dim() == 1:
             p.data.normal_(0, 0.1)
-    x = torch.randn(3, 8, 6, 6, requires_grad=True)
-    h = torch.randn(3, 16, 6, 6, requires_grad=True)
+    x = torch.randn(3, 8, 4, 8, requires_grad=True)       # H != W on purpose
+    h = torch.randn(3, 16, 4, 8, requires_grad=True)
     put_sd(st, "cell.sd0", cell)
     st["cell.in.x"], st["cell.in.h"] = npy(x), npy(h)
     y0 = cell(x)           # prev_state None -> zeros (ConvGRU.py:31-44)
@@ -188,7 +188,7 @@ def f4_convgru(R):
         if p.dim() == 1:
             p.data.normal_(0, 0.1)
     T = 4
-    xs = torch.randn(T, 2, 8, 6, 6, requires_grad=True)
+    xs = torch.randn(T, 2, 8, 8, 4, requires_grad=True)
     put_sd(st, "gru.sd0", gru)
     st["gru.in.xs"] = npy(xs)
     hidden, outs = None, []
