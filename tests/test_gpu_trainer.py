@@ -1,0 +1,134 @@
+"""GPU parity of the full G + D_s + D_t training step (HIP path) against the unmodified reference
+Trainer (golden F9: two steps, hinge and wgan-gp; F10: config-1 plumbing, three steps).
+
+Exact mode (f32 MFMA): the six loss terms per step within 2e-3 relative / 2e-4 absolute of the
+reference (two optimizer steps deep; the fixtures amplify fp32 rounding ~100x, see
+test_gpu_modules.GEN_TOL), post-step parameter checksums within 3e-2 (see comment), named gradients rel-L2 < 2e-2.
+bf16 mode: losses within 0.15 absolute (smoke-level: the ch=2 fixtures are ill-conditioned).
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_trainer(g, base, adv, dtype):
+    from dvd_gan_amd.train_step import Trainer
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    lr = float(g["meta.lr"])
+    cfg = argparse.Namespace(adv_loss=adv, z_dim=z_dim, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
+                             total_epoch=1, d_iters=1, batch_size=B, g_lr=lr, d_lr=lr, beta1=0.0, beta2=0.9,
+                             n_class=n_class, k_sample=k)
+    tr = Trainer([], cfg, device=torch.device(DEV), compute_dtype=dtype)
+    for net, tag in ((tr.G, "G"), (tr.D_s, "Ds"), (tr.D_t, "Dt")):
+        net.load_state_dict({kk: torch.as_tensor(v) for kk, v in sub(base, tag + ".sd0").items()})
+        net.train()
+    return tr, steps
+
+
+def rel_l2(a, b):
+    b = torch.as_tensor(b).double()
+    return float((a.detach().double().cpu() - b).norm() / (b.norm() + 1e-30))
+
+
+def check_step0_grads(tr, g):
+    """Named gradients the reference held when each optimizer stepped in step 0 (no Adam involved
+    yet): D_s / D_t gradients of their own updates, G gradients through the UPDATED discriminators."""
+    n = 0
+    for tag, net, opt in (("Ds", tr.D_s, tr.ds_optimizer), ("Dt", tr.D_t, tr.dt_optimizer), ("G", tr.G, tr.g_optimizer)):
+        named = dict(net.named_parameters())
+        for k, v in sub(g, f"grad.0.{tag}").items():
+            r = rel_l2(tr._grad_snap[tag][k], v)
+            assert r < 1e-2, (tag, k, r)
+            n += 1
+    assert n >= 10
+
+
+def run(g, base, adv, dtype):
+    tr, steps = make_trainer(g, base, adv, dtype)
+    # snapshot gradients right before each Adam launch of step 0
+    tr._grad_snap = {}
+    for tag, net, opt in (("Ds", tr.D_s, tr.ds_optimizer), ("Dt", tr.D_t, tr.dt_optimizer), ("G", tr.G, tr.g_optimizer)):
+        def wrap(opt=opt, net=net, tag=tag, orig=opt.step):
+            def stepper():
+                if tag not in tr._grad_snap:
+                    tr._grad_snap[tag] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+                orig()
+            return stepper
+        opt.step = wrap()
+    nb = len([k for k in base if k.startswith("in.real.")])
+    out = []
+    for s in range(steps):
+        draws = {"perm_real": base[f"in.perm_real.{s}"], "z": base[f"in.z.{s}"], "z_class": base[f"in.z_class.{s}"],
+                 "perm_fake": base[f"in.perm_fake.{s}"]}
+        losses = tr.train_step(torch.as_tensor(base[f"in.real.{s % nb}"]), torch.as_tensor(base[f"in.labels.{s % nb}"]), draws)
+        out.append([float(v.detach()) for v in losses])
+        want = g[f"out.losses.{s}"]
+        if dtype == torch.float32:
+            # step 0 is a pure forward/backward comparison.  From step 1 on the weights have been
+            # through Adam, whose first updates are ~lr*sign(g): elements whose gradient is at the
+            # rounding-noise level flip freely.  Measured with the CPU oracle on this fixture (fp64
+            # vs fp32, and fp64 with 1e-7 relative weight noise) that moves the step-1 losses by
+            # ~2e-3; the HIP path reorders more sums than that, so later steps get atol 2e-2.
+            if s == 0:
+                np.testing.assert_allclose(out[-1], want, rtol=2e-3, atol=2e-4, err_msg="losses step 0")
+            else:
+                np.testing.assert_allclose(out[-1], want, rtol=1e-2, atol=2e-2, err_msg=f"losses step {s}")
+            keys = [str(x) for x in g["meta.psum_keys.G"]]
+            sd = tr.G.state_dict()
+            got = np.array([float(sd[kk].double().abs().sum()) for kk in keys])
+            ref = g[f"out.psum.{s}.G"]
+            big = ref > 1.0                  # zero-initialised biases are sums of +-lr noise steps
+            np.testing.assert_allclose(got[big], ref[big], rtol=1e-3 if s == 0 else 2e-2, err_msg=f"G checksums step {s}")
+        else:
+            np.testing.assert_allclose(out[-1], want, atol=0.15, err_msg=f"losses step {s}")
+    return tr, out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trainer_hinge_two_steps(golden, dtype):
+    g = golden("f9_trainer_hinge")
+    tr, _ = run(g, g, "hinge", dtype)
+    if dtype == torch.float32:
+        check_step0_grads(tr, g)
+        # (gradients of the SECOND generator update are not compared: on this fixture the CPU oracle
+        #  run in fp64 differs from its own fp32 run by 70-130 % there -- chaotic after one Adam step)
+        for tag, net in (("G", tr.G), ("Ds", tr.D_s), ("Dt", tr.D_t)):      # SN u/v, BN buffers after 2 steps
+            sd = net.state_dict()
+            for k, v in sub(g, tag + ".sd1").items():
+                if not k.endswith("num_batches_tracked"):
+                    assert float((sd[k].double().cpu() - torch.as_tensor(v).double()).norm() / (np.linalg.norm(v) + 1e-30)) < 5e-2, k
+
+
+def test_trainer_wgangp_two_steps(golden):
+    g = golden("f9_trainer_wgangp")
+    tr, _ = run(g, golden("f9_trainer_hinge"), "wgan-gp", torch.float32)
+    check_step0_grads(tr, g)
+
+
+def test_config1_plumbing_three_steps(golden):
+    g = golden("f10_config1")
+    run(g, g, "hinge", torch.float32)
+
+
+def test_adam_kernel_matches_torch():
+    """dvd_adam_step against torch.optim.Adam (CPU) on random data, 3 steps, betas of the reference."""
+    from dvd_gan_amd import kern as K
+    torch.manual_seed(3)
+    p0 = torch.randn(10007)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-3, betas=(0.0, 0.9))
+    p = p0.to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        gr = torch.randn(10007) * 10 ** float(torch.randint(-6, 1, ()))
+        ref.grad = gr.clone()
+        opt.step()
+        K.adam_step(p, gr.to(DEV), m, v, 2e-3, 0.0, 0.9, 1e-8, step)
+        assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6
