@@ -9,7 +9,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bf16_t;   // raw storage
 
-struct alignas(16) u32x4 { uint32_t x, y, z, w; };
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // a real register vector (a struct here ends up in scratch)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN kept quiet

@@ -35,6 +35,11 @@ extern "C" {
 #define DVD_ACT_SIGMOID 3
 
 int dvd_abi_version(void);              /* bumps when a signature changes                      */
+/* Optional measurement aid for bench.py: bracket every conv launch with HIP events on its stream.
+ * kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Report drains the records,
+ * returns the launch count, total milliseconds and total algorithmic FLOPs (2*M*Cout*C*taps). */
+void dvd_prof_enable(int on);
+long long dvd_prof_report(int kind, double* total_ms, double* total_flops);
 const char* dvd_strerror(int code);
 
 /* ------------------------------------------------------------------------------------------
