@@ -238,8 +238,8 @@ struct WgK {
 
 // D[co][ci] = sum over rows m of dy[m][co] * x[pos(m)+tap][ci].  The reduction index (rows) is the
 // MFMA K dimension, so both operand tiles must be K(row)-contiguous per channel in LDS:
-//   bf16: each thread loads 2 channels x 8 consecutive rows as dwords, transposes them in
-//         registers (4 packed dwords per channel) and stores two 16-byte LDS rows;
+//   bf16: tiles are staged in their natural [row][channel] image with 16-byte loads and the
+//         fragments are built by the LDS transpose read ds_read_b64_tr_b16;
 //   f32 : the natural [row][channel] image already matches the 32x32x2 fragment (1 float/lane).
 template <typename T>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
@@ -279,96 +279,104 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
     };
 
     if constexpr (kBf16) {
-        const int cp = tid & 63, pg = tid >> 6;          // channel pair, group of 8 rows
-        const int cy = co0 + 2 * cp, cx = ci0 + 2 * cp;
+        // Natural [row][channel] LDS image (row stride 320 B = 256 B of channels + 64 B: the four
+        // rows a 16-lane group touches land on disjoint bank quarters).  MFMA fragments need 8
+        // consecutive ROWS of one channel per lane: ds_read_b64_tr_b16 delivers exactly that
+        // (each 16-lane group reads a 4-row x 16-channel block and hands lane i column i).
+        constexpr int RS = 320;
+        const int rr = tid >> 4, chk = tid & 15;          // staged rows rr, rr+16; 16-byte chunk chk
+        const int cy = co0 + chk * 8, cx = ci0 + chk * 8;
         const bool cyv = cy < p.Cy, cxv = cx < p.C;
-        uint32_t dA[8], dB[8];
-        uint32_t mA = 0, mB = 0;        // validity bits of the 8 staged rows (loads themselves are unconditional)
-        auto gload = [&](int mk) {
-            mA = 0; mB = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = mk + pg * 8 + j;
-                const bool va = cyv && m < m_end;
-                const size_t oa = va ? ((size_t)m * p.ldy + cy) : 0;
-                dA[j] = *reinterpret_cast<const uint32_t*>(p.dy + oa * 2);
-                mA |= (uint32_t)va << j;
-                bool vb;
-                size_t ob = xoff(m, vb);
-                vb = vb && cxv;
-                ob = vb ? ob + cx : 0;
-                dB[j] = *reinterpret_cast<const uint32_t*>(p.x + ob * 2);
-                mB |= (uint32_t)vb << j;
-            }
+        u32x4 a0, a1, b0, b1;
+        bool oa0 = false, oa1 = false, ob0 = false, ob1 = false;
+#define WG_GLOAD(mk)                                                                              \
+    do {                                                                                          \
+        const int m0_ = (mk) + rr, m1_ = (mk) + rr + 16;                                          \
+        oa0 = cyv && m0_ < m_end; oa1 = cyv && m1_ < m_end;                                       \
+        const size_t oy0_ = oa0 ? ((size_t)m0_ * p.ldy + cy) : 0, oy1_ = oa1 ? ((size_t)m1_ * p.ldy + cy) : 0; \
+        a0 = *reinterpret_cast<const u32x4*>(p.dy + oy0_ * 2);                                     \
+        a1 = *reinterpret_cast<const u32x4*>(p.dy + oy1_ * 2);                                     \
+        size_t ox0_ = xoff(m0_, ob0), ox1_ = xoff(m1_, ob1);                                       \
+        ob0 = ob0 && cxv; ob1 = ob1 && cxv;                                                        \
+        ox0_ = ob0 ? ox0_ + cx : 0; ox1_ = ob1 ? ox1_ + cx : 0;                                    \
+        b0 = *reinterpret_cast<const u32x4*>(p.x + ox0_ * 2);                                      \
+        b1 = *reinterpret_cast<const u32x4*>(p.x + ox1_ * 2);                                      \
+    } while (0)
+#define WG_LSTORE(buf)                                                                            \
+    do {                                                                                          \
+        const u32x4 zero_ = {0u, 0u, 0u, 0u};                                                     \
+        u32x4 vb0_ = p.relu_in ? relu16_bf16(b0) : b0, vb1_ = p.relu_in ? relu16_bf16(b1) : b1;   \
+        *reinterpret_cast<u32x4*>(&smem[buf][0][rr * RS + chk * 16]) = oa0 ? a0 : zero_;           \
+        *reinterpret_cast<u32x4*>(&smem[buf][0][(rr + 16) * RS + chk * 16]) = oa1 ? a1 : zero_;    \
+        *reinterpret_cast<u32x4*>(&smem[buf][1][rr * RS + chk * 16]) = ob0 ? vb0_ : zero_;         \
+        *reinterpret_cast<u32x4*>(&smem[buf][1][(rr + 16) * RS + chk * 16]) = ob1 ? vb1_ : zero_;  \
+    } while (0)
+        // per-lane byte offset of its chunk inside a 4-row x 16-channel block of the fragment
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int frag_off = ((g16 >> 1) * 8 + (i16 >> 2)) * RS + ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;
+        auto frag = [&](const char* tile, int col0, int kb) -> bf16x8 {
+            typedef __attribute__((ext_vector_type(4))) short s16x4;
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const char* pz = tile + frag_off + kb * RS + col0 * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pz);
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pz + 4 * RS));
+            s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(bf16x8, f);
         };
-        auto lstore = [&](int buf) {
+        auto mma = [&](int buf) {
+            const char* At = &smem[buf][0][0];
+            const char* Bt = &smem[buf][1][0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                dA[j] = (mA >> j) & 1u ? dA[j] : 0u;
-                uint32_t b = p.relu_in ? relu2_bf16(dB[j]) : dB[j];
-                dB[j] = (mB >> j) & 1u ? b : 0u;
+            for (int kb = 0; kb < 32; kb += 16) {
+                const bf16x8 fa0 = frag(At, wm * 64, kb), fa1 = frag(At, wm * 64 + 32, kb);
+                const bf16x8 fb0 = frag(Bt, wn * 64, kb), fb1 = frag(Bt, wn * 64 + 32, kb);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
             }
-            u32x4 lo, hi;
-            lo.x = (dA[0] & 0xffffu) | (dA[1] << 16); hi.x = (dA[0] >> 16) | (dA[1] & 0xffff0000u);
-            lo.y = (dA[2] & 0xffffu) | (dA[3] << 16); hi.y = (dA[2] >> 16) | (dA[3] & 0xffff0000u);
-            lo.z = (dA[4] & 0xffffu) | (dA[5] << 16); hi.z = (dA[4] >> 16) | (dA[5] & 0xffff0000u);
-            lo.w = (dA[6] & 0xffffu) | (dA[7] << 16); hi.w = (dA[6] >> 16) | (dA[7] & 0xffff0000u);
-            *reinterpret_cast<u32x4*>(&smem[buf][0][(2 * cp) * ROWB + pg * 16]) = lo;
-            *reinterpret_cast<u32x4*>(&smem[buf][0][(2 * cp + 1) * ROWB + pg * 16]) = hi;
-            lo.x = (dB[0] & 0xffffu) | (dB[1] << 16); hi.x = (dB[0] >> 16) | (dB[1] & 0xffff0000u);
-            lo.y = (dB[2] & 0xffffu) | (dB[3] << 16); hi.y = (dB[2] >> 16) | (dB[3] & 0xffff0000u);
-            lo.z = (dB[4] & 0xffffu) | (dB[5] << 16); hi.z = (dB[4] >> 16) | (dB[5] & 0xffff0000u);
-            lo.w = (dB[6] & 0xffffu) | (dB[7] << 16); hi.w = (dB[6] >> 16) | (dB[7] & 0xffff0000u);
-            *reinterpret_cast<u32x4*>(&smem[buf][1][(2 * cp) * ROWB + pg * 16]) = lo;
-            *reinterpret_cast<u32x4*>(&smem[buf][1][(2 * cp + 1) * ROWB + pg * 16]) = hi;
         };
         if (m_begin < m_end) {
-            gload(m_begin);
-            lstore(0);
+            WG_GLOAD(m_begin);
+            WG_LSTORE(0);
             __syncthreads();
             int buf = 0;
             for (int mk = m_begin; mk < m_end; mk += BKW, buf ^= 1) {
                 const bool more = mk + BKW < m_end;
-                if (more) gload(mk + BKW);
-                mma_rowmajor<T>(&smem[buf][0][(wm * 64 + (lane & 31)) * ROWB],
-                                &smem[buf][1][(wn * 64 + (lane & 31)) * ROWB], lane, acc);
-                if (more) lstore(buf ^ 1);
+                if (more) WG_GLOAD(mk + BKW);
+                mma(buf);
+                if (more) WG_LSTORE(buf ^ 1);
                 __syncthreads();
             }
         }
+#undef WG_GLOAD
+#undef WG_LSTORE
     } else {
         // f32: LDS image [16 rows][WG_LD floats]; thread stages rows kr, kr+8, 16-byte chunk ch
         const int ch = tid & 31, kr = tid >> 5;
         const int cy = co0 + ch * 4, cx = ci0 + ch * 4;
         const bool cyv = cy < p.Cy, cxv = cx < p.C;
-        u32x4 ra[2], rb[2];
-        bool oka[2], okb[2];
+        u32x4 a0, a1, b0, b1;
+        bool oa0 = false, oa1 = false, ob0 = false, ob1 = false;
         auto gload = [&](int mk) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = mk + kr + 8 * i;
-                const bool va = cyv && m < m_end;
-                const size_t oa = va ? ((size_t)m * p.ldy + cy) : 0;
-                ra[i] = *reinterpret_cast<const u32x4*>(p.dy + oa * 4);
-                oka[i] = va;
-                bool vb;
-                size_t ob = xoff(m, vb);
-                vb = vb && cxv;
-                ob = vb ? ob + cx : 0;
-                rb[i] = *reinterpret_cast<const u32x4*>(p.x + ob * 4);
-                okb[i] = vb;
-            }
+            const int m0_ = mk + kr, m1_ = mk + kr + 8;
+            oa0 = cyv && m0_ < m_end; oa1 = cyv && m1_ < m_end;
+            const size_t oy0 = oa0 ? ((size_t)m0_ * p.ldy + cy) : 0, oy1 = oa1 ? ((size_t)m1_ * p.ldy + cy) : 0;
+            a0 = *reinterpret_cast<const u32x4*>(p.dy + oy0 * 4);
+            a1 = *reinterpret_cast<const u32x4*>(p.dy + oy1 * 4);
+            size_t ox0 = xoff(m0_, ob0), ox1 = xoff(m1_, ob1);
+            ob0 = ob0 && cxv; ob1 = ob1 && cxv;
+            ox0 = ob0 ? ox0 + cx : 0; ox1 = ob1 ? ox1 + cx : 0;
+            b0 = *reinterpret_cast<const u32x4*>(p.x + ox0 * 4);
+            b1 = *reinterpret_cast<const u32x4*>(p.x + ox1 * 4);
         };
         auto lstore = [&](int buf) {
             const u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const u32x4 va = oka[i] ? ra[i] : zero;
-                u32x4 vb = p.relu_in ? relu16_f32(rb[i]) : rb[i];
-                vb = okb[i] ? vb : zero;
-                *reinterpret_cast<u32x4*>(&smem[buf][0][((kr + 8 * i) * WG_LD + ch * 4) * 4]) = va;
-                *reinterpret_cast<u32x4*>(&smem[buf][1][((kr + 8 * i) * WG_LD + ch * 4) * 4]) = vb;
-            }
+            const u32x4 vb0 = p.relu_in ? relu16_f32(b0) : b0, vb1 = p.relu_in ? relu16_f32(b1) : b1;
+            *reinterpret_cast<u32x4*>(&smem[buf][0][(kr * WG_LD + ch * 4) * 4]) = oa0 ? a0 : zero;
+            *reinterpret_cast<u32x4*>(&smem[buf][0][((kr + 8) * WG_LD + ch * 4) * 4]) = oa1 ? a1 : zero;
+            *reinterpret_cast<u32x4*>(&smem[buf][1][(kr * WG_LD + ch * 4) * 4]) = ob0 ? vb0 : zero;
+            *reinterpret_cast<u32x4*>(&smem[buf][1][((kr + 8) * WG_LD + ch * 4) * 4]) = ob1 ? vb1 : zero;
         };
         auto mma = [&](int buf) {
             const float* As = reinterpret_cast<const float*>(&smem[buf][0][0]) + wm * 64 + (lane & 31);
