@@ -100,16 +100,31 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ld
     }
     dgp = blk_sum(dgp, sh);
     if (tid == 0 && dgamma) atomicAdd(dgamma, dgp);
-    // dA[i][j] = gamma * sum_c dy[i][c] v[j][c]
-    for (int idx = tid; idx < QB * N; idx += 256) {
-        const int i = idx / N, j = idx - i * N;
-        float s = 0.f;
-        if (i0 + i < N) {
-            const T* d = dy + ((size_t)f * N + i0 + i) * ldx;
-            const T* v = qf + (size_t)j * ldq + voff;
-            for (int c = 0; c < C; ++c) s += ldf(d + c) * ldf(v + c);
+    // dA[i][j] = gamma * sum_c dy[i][c] v[j][c]: the block's QB rows of dy are staged in LDS as
+    // floats; thread j streams its v row with 16-byte loads and keeps QB accumulators.
+    float* dyl = S + QB * N;                        // [QB][C]
+    for (int idx = tid; idx < QB * C; idx += 256) {
+        const int i = idx / C, c = idx - i * C;
+        dyl[idx] = (i0 + i < N) ? ldf(dy + ((size_t)f * N + i0 + i) * ldx + c) : 0.f;
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) {
+        float acc[QB];
+#pragma unroll
+        for (int i = 0; i < QB; ++i) acc[i] = 0.f;
+        const T* v = qf + (size_t)j * ldq + voff;
+        for (int c = 0; c < C; c += 8) {
+            float vv[8];
+            load8<T>(v + c, vv);                    // C is a multiple of 8, voff too
+#pragma unroll
+            for (int i = 0; i < QB; ++i) {
+                const float* d = dyl + i * C + c;
+                acc[i] += d[0] * vv[0] + d[1] * vv[1] + d[2] * vv[2] + d[3] * vv[3] + d[4] * vv[4] + d[5] * vv[5] +
+                          d[6] * vv[6] + d[7] * vv[7];
+            }
         }
-        S[idx] = s * g;
+#pragma unroll
+        for (int i = 0; i < QB; ++i) S[i * N + j] = acc[i] * g;
     }
     __syncthreads();
     // dS = A * (dA - sum_j A dA)
@@ -204,10 +219,12 @@ extern "C" int dvd_attention_backward(int dtype, const void* qkv, int ldq, int d
                                       int ldx, int C, const float* gamma, const void* att_out, const float* A,
                                       float* dS, void* dqkv, float* dgamma, long long frames, int N, void* stream) {
     if (!qkv || !dy || !gamma || !att_out || !A || !dS || !dqkv || frames <= 0 || N <= 0) return DVD_E_ARG;
-    if ((size_t)QB * N * sizeof(float) > 64 * 1024 || frames > 65535) return DVD_E_SHAPE;
+    if ((size_t)QB * (N + C) * sizeof(float) > 64 * 1024 || frames > 65535) return DVD_E_SHAPE;
     dim3 grid(cdiv(N, QB), (unsigned)frames);
     const size_t sh = (size_t)QB * N * sizeof(float);
-    BY_DTYPE(dtype, attn_bwd_rows_kernel<T><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)dy, ldx, C,
+    if (C & 7) return DVD_E_SHAPE;
+    const size_t sh_rows = sh + (size_t)QB * C * sizeof(float);
+    BY_DTYPE(dtype, attn_bwd_rows_kernel<T><<<grid, 256, sh_rows, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)dy, ldx, C,
                                                                    gamma, (const T*)att_out, A, dS, (T*)dqkv, dgamma, N));
     BY_DTYPE(dtype, attn_bwd_cols_kernel<T><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)dy, ldx, C,
                                                                    gamma, A, dS, (T*)dqkv, N));

@@ -1,0 +1,59 @@
+"""world_size=2 gloo test (CPU) of the data-parallel pieces: batch sharding and the gradient exchange.
+Each rank computes the discriminator gradients of ITS shard with the CPU oracle; after
+GradExchange (all-reduce mean on one flat buffer) both ranks must hold the gradient of the GLOBAL batch
+(loss means over equal shards average exactly; D has no batch coupling)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden, sub
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ds_grads(g, x, cls):
+    from oracle import dvdgan_cpu as O
+    sd = O.make_state(sub(sub(g, "ds"), "sd0"))
+    loss = O.adv_loss(O.spatial_disc(sd, x, cls), True, "hinge")
+    loss.backward()
+    keys = sorted(k for k in sd if O.is_trainable(k))
+    return keys, torch.cat([sd[k].grad.reshape(-1) for k in keys])
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from dvd_gan_amd import dist as D
+    r, w, dev = D.init_from_env("gloo")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    g = load_golden("f7_discriminators")
+    x, cls = torch.as_tensor(g["ds.in.x"]), torch.as_tensor(g["ds.in.cls"])       # global batch of 2 clips
+    xs, cs = D.shard(x, rank, world), D.shard(cls, rank, world)
+    assert xs.shape[0] == 1
+    _, flat = _ds_grads(g, xs, cs)
+    ex = D.GradExchange()
+    ex.start("Ds", flat)
+    ex.finish("Ds")
+    out[rank] = flat.numpy().copy()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_equals_global_batch():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = load_golden("f7_discriminators")
+    _, full = _ds_grads(g, torch.as_tensor(g["ds.in.x"]), torch.as_tensor(g["ds.in.cls"]))
+    np.testing.assert_allclose(out[0], out[1], rtol=0, atol=0)
+    np.testing.assert_allclose(out[0], full.numpy(), rtol=2e-4, atol=2e-6)
