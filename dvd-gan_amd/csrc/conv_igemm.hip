@@ -81,55 +81,138 @@ struct ConvK {
     int up2, relu_in, act, out_f32;
 };
 
-// One staged row of the activation tile: where it lives and whether it is inside the frame.
-struct RowPos { int m, x, y, t, f; bool valid; };
+// LDS tile image: 64-byte rows (one K chunk), no padding; the 16-byte slot of a row is XOR-swizzled
+// with bits 2..3 of the row index.  Conflict-free for the loader's ds_write_b128 (8 consecutive lanes
+// = 2 rows x 4 slots = all 32 banks) and for the fragment ds_read_b128 (a 16-lane group reads 16 rows
+// whose (row&3, slot) pairs are all distinct).  Measured before this layout (80-byte padded rows):
+// SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE, all of it on the stores.
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <typename T>
-__device__ __forceinline__ void conv_load_row(const ConvK& p, const RowPos& r, int dt, int dy, int dx, int delta, int c,
-                                              bool cv, u32x4& v, bool& ok) {
-    int yy = r.y + dy, xx = r.x + dx;
-    const int tt = r.t + dt;
-    ok = r.valid && cv && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && (unsigned)tt < (unsigned)p.T;
-    // input row index: same grid as the output (m + tap delta) unless the input is the half-res image
-    int row = p.up2 ? ((r.f + dt) * p.Hin + (yy >> 1)) * p.Win + (xx >> 1) : r.m + delta;
-    row = ok ? row : 0;
-    const size_t off = (size_t)(unsigned)row * (size_t)(unsigned)p.ldi + (unsigned)(ok ? c : 0);
-    v = *reinterpret_cast<const u32x4*>(p.in + off * sizeof(T));
-}
-template <typename T>
-__device__ __forceinline__ void conv_load_w(const ConvK& p, int tap, int co, bool cov, int c, bool cv, u32x4& v, bool& ok) {
-    ok = cov && cv;
-    const size_t off = ok ? ((size_t)(unsigned)(tap * p.Cout + co) * (size_t)(unsigned)p.C + (unsigned)c) : 0;
-    v = *reinterpret_cast<const u32x4*>(p.w + off * sizeof(T));
+// acc[tm][tn] += A(TM*32 rows of this wave) x B(64 cols of this wave) over one 64-byte K chunk.
+template <typename T, int TM>
+__device__ __forceinline__ void mma_swz(const char* At, const char* Bt, int arow, int brow, int lane,
+                                        f32x16 (&acc)[TM][2]) {
+    const int kh = lane >> 5;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = kk * 2 + kh;
+            bf16x8 b[2], a[TM];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) b[tn] = *reinterpret_cast<const bf16x8*>(Bt + lds_off(brow + tn * 32, slot));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const bf16x8*>(At + lds_off(arow + tm * 32, slot));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = kk * 2 + kh;                 // float index 0..15 inside the 64-byte row
+            float b[2], a[TM];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+                b[tn] = *reinterpret_cast<const float*>(Bt + lds_off(brow + tn * 32, k >> 2) + (k & 3) * 4);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                a[tm] = *reinterpret_cast<const float*>(At + lds_off(arow + tm * 32, k >> 2) + (k & 3) * 4);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
 }
 
+// Epilogue for 8 consecutive output columns of one row (values read from the wave's LDS staging area).
 template <typename T>
+__device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, int row, int col, int z) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[k];
+    const int nvalid = min(8, p.Cout - col);
+    if (p.ws) {                                                    // raw split-K partial sums
+        float* dst = p.ws + ((size_t)z * p.M + row) * p.Cout + col;
+        if (nvalid == 8 && !(p.Cout & 3)) {
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            for (int k = 0; k < nvalid; ++k) dst[k] = v[k];
+        }
+        return;
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (k < nvalid) ? p.bias[col + k] : 0.f;
+    }
+    if (p.res) {
+        float rv[8];
+        load8<T>(reinterpret_cast<const T*>(p.res) + (size_t)row * p.ldres + col, rv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += rv[k];
+    }
+    if (p.act == DVD_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    } else if (p.act == DVD_ACT_TANH) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+    } else if (p.act == DVD_ACT_SIGMOID) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 1.f / (1.f + __expf(-v[k]));
+    }
+    if (p.mask) {
+        float mv[8];
+        load8<T>(reinterpret_cast<const T*>(p.mask) + (size_t)row * p.ldmask + col, mv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = mv[k] > 0.f ? v[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (k < nvalid) ? v[k] : 0.f;  // padded channels stay exactly zero
+    if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo + col, v);
+    else store8<T>(reinterpret_cast<T*>(p.out) + (size_t)row * p.ldo + col, v);
+}
+
+// Workgroup = 2 x 2 waves, wave tile = (TM*32) x 64  =>  block tile BM = TM*64 rows x 128 columns.
+// TM = 4 (256 x 128) is the production shape: 16 MFMAs per wave between barriers and 6 instead of 8
+// fragment reads per 8 MFMAs; TM = 2 (128 x 128) serves problems with few rows.
+template <typename T, int TM>
 __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
     constexpr int E16 = ElemTraits<T>::kPer16B;
     constexpr int BK = 4 * E16;
-    __shared__ __attribute__((aligned(16))) char smem[2][2][TILEB];
+    constexpr int BMt = TM * 64;
+    constexpr int NA = BMt / 64;                       // activation rows staged per thread
+    constexpr int ABYTES = BMt * 64, BBYTES = BN * 64;
+    __shared__ __attribute__((aligned(16))) char smem[2][ABYTES + BBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int mt = blockIdx.x / p.tilesN, nt = blockIdx.x - mt * p.tilesN;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * BMt, n0 = nt * BN;
     const int z = blockIdx.z;
     const int per = (p.nk + p.nsplit - 1) / p.nsplit;
     const int k_begin = z * per;
     const int k_end = min(p.nk, k_begin + per);
+    const size_t esz = sizeof(T);
 
-    // ---- loader coordinates: this thread stages rows r0 and r0+64, 16-byte chunk q ----
+    // ---- loader coordinates: this thread stages rows r0 + 64*i, 16-byte slot q ----
     const int q = tid & 3, r0 = tid >> 2;
-    RowPos rp0, rp1;
-    {
-        const int m = m0 + r0;
-        rp0.m = m; rp0.valid = m < p.M; rp0.x = m & (p.W - 1); rp0.y = (m >> p.logW) & (p.H - 1);
-        rp0.f = m >> (p.logW + p.logH); rp0.t = p.kt > 1 ? rp0.f % p.T : 0;
-        const int m2 = m + 64;
-        rp1.m = m2; rp1.valid = m2 < p.M; rp1.x = m2 & (p.W - 1); rp1.y = (m2 >> p.logW) & (p.H - 1);
-        rp1.f = m2 >> (p.logW + p.logH); rp1.t = p.kt > 1 ? rp1.f % p.T : 0;
+    int am[NA], ax[NA], ay[NA], at[NA];
+    bool av[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        am[i] = m; av[i] = m < p.M;
+        ax[i] = m & (p.W - 1); ay[i] = (m >> p.logW) & (p.H - 1);
+        at[i] = p.kt > 1 ? (m >> (p.logW + p.logH)) % p.T : 0;
     }
     const int co0 = n0 + r0, co1 = n0 + r0 + 64;
     const bool cov0 = co0 < p.Cout, cov1 = co1 < p.Cout;
+    const size_t ldb = (size_t)p.ldi * esz;            // input row pitch in bytes
+    const size_t wrow0 = ((size_t)co0 * p.C + q * E16) * esz, wrow1 = ((size_t)co1 * p.C + q * E16) * esz;
     // wave-uniform K-step state (tap decomposition kept incrementally)
     int tap = 0, cc = 0, it = 0, iy = 0, ix = 0;
     if (k_begin < k_end) {
@@ -139,43 +222,66 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
     }
     // Loads are issued UNCONDITIONALLY from a clamped (always valid) address and masked when they
     // are written to LDS: a load inside a divergent branch makes hipcc drain vmcnt(0) right there,
-    // which serialises the four loads of a K step and keeps them from overlapping the MFMAs.
-    u32x4 a0, a1, b0, b1;
-    bool oa0 = false, oa1 = false, ob0 = false, ob1 = false;
-#define CONV_GLOAD()                                                                                   \
-    do {                                                                                               \
-        const int dt_ = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx_ = ix - (p.kw >> 1);              \
-        const int delta_ = (dt_ * p.H + dy_) * p.W + dx_;                                              \
-        const int c_ = cc * BK + q * E16;                                                              \
-        const bool cv_ = c_ < p.C;                                                                     \
-        conv_load_row<T>(p, rp0, dt_, dy_, dx_, delta_, c_, cv_, a0, oa0);                             \
-        conv_load_row<T>(p, rp1, dt_, dy_, dx_, delta_, c_, cv_, a1, oa1);                             \
-        conv_load_w<T>(p, tap, co0, cov0, c_, cv_, b0, ob0);                                           \
-        conv_load_w<T>(p, tap, co1, cov1, c_, cv_, b1, ob1);                                           \
-        if (++cc == p.kchunks) {                                                                       \
-            cc = 0; ++tap;                                                                             \
-            if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }                          \
-        }                                                                                              \
-    } while (0)
-#define CONV_LSTORE(buf)                                                                               \
-    do {                                                                                               \
-        const u32x4 zero_ = {0u, 0u, 0u, 0u};                                                          \
-        u32x4 va0_ = p.relu_in ? relu16<T>(a0) : a0, va1_ = p.relu_in ? relu16<T>(a1) : a1;           \
-        va0_ = oa0 ? va0_ : zero_; va1_ = oa1 ? va1_ : zero_;                                          \
-        *reinterpret_cast<u32x4*>(&smem[buf][0][r0 * ROWB + q * 16]) = va0_;                           \
-        *reinterpret_cast<u32x4*>(&smem[buf][0][(r0 + 64) * ROWB + q * 16]) = va1_;                    \
-        *reinterpret_cast<u32x4*>(&smem[buf][1][r0 * ROWB + q * 16]) = ob0 ? b0 : zero_;               \
-        *reinterpret_cast<u32x4*>(&smem[buf][1][(r0 + 64) * ROWB + q * 16]) = ob1 ? b1 : zero_;        \
-    } while (0)
+    // which serialises the loads of a K step and keeps them from overlapping the MFMAs.
+    u32x4 ra[NA], rb0, rb1;
+    bool oa[NA], ob0 = false, ob1 = false;
+    auto gload = [&]() __attribute__((always_inline)) {
+        const int dt_ = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx_ = ix - (p.kw >> 1);
+        const int c_ = cc * BK + q * E16;
+        const bool cv_ = c_ < p.C;
+        // wave-uniform part of the address: tap shift + channel chunk (the per-lane slot q is in c_)
+        const long long delta_ = ((long long)(dt_ * p.H + dy_) * p.W + dx_) * (long long)ldb + (long long)c_ * (long long)esz;
+        const char* abase_ = p.in + delta_;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_, tt_ = at[i] + dt_;
+            const bool ok_ = av[i] && cv_ && (unsigned)yy_ < (unsigned)p.H && (unsigned)xx_ < (unsigned)p.W &&
+                             (unsigned)tt_ < (unsigned)p.T;
+            const char* ptr_;
+            if (p.up2) {
+                const int f_ = am[i] >> (p.logW + p.logH);
+                const int row_ = ((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1);
+                ptr_ = p.in + (size_t)(unsigned)(ok_ ? row_ : 0) * ldb + (size_t)(ok_ ? c_ : 0) * esz;
+            } else {
+                ptr_ = abase_ + (size_t)(unsigned)am[i] * ldb;
+                ptr_ = ok_ ? ptr_ : p.in;
+            }
+            ra[i] = *reinterpret_cast<const u32x4*>(ptr_);
+            oa[i] = ok_;
+        }
+        const char* wbase_ = p.w + ((size_t)tap * p.Cout * p.C + (size_t)cc * BK) * esz;
+        ob0 = cov0 && cv_; ob1 = cov1 && cv_;
+        rb0 = *reinterpret_cast<const u32x4*>(ob0 ? wbase_ + wrow0 : p.w);
+        rb1 = *reinterpret_cast<const u32x4*>(ob1 ? wbase_ + wrow1 : p.w);
+        if (++cc == p.kchunks) {
+            cc = 0; ++tap;
+            if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        const u32x4 zero_ = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x4 v_ = p.relu_in ? relu16<T>(ra[i]) : ra[i];
+            v_ = oa[i] ? v_ : zero_;
+            *reinterpret_cast<u32x4*>(&smem[buf][lds_off(r0 + 64 * i, q)]) = v_;
+        }
+        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0, q)]) = ob0 ? rb0 : zero_;
+        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0 + 64, q)]) = ob1 ? rb1 : zero_;
+    };
+#define CONV_GLOAD() gload()
+#define CONV_LSTORE(buf) lstore(buf)
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int b = 0; b < 2; ++b) acc[a][b] = zacc;   // (a per-element loop of 128 stores is not unrolled -> scratch)
+    }
 
+    const int arow = wm * (TM * 32) + (lane & 31), brow = wn * 64 + (lane & 31);
     if (k_begin < k_end) {
         CONV_GLOAD();
         CONV_LSTORE(0);
@@ -184,8 +290,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
             const int buf = (ks - k_begin) & 1;
             const bool more = ks + 1 < k_end;
             if (more) CONV_GLOAD();
-            mma_rowmajor<T>(&smem[buf][0][(wm * 64 + (lane & 31)) * ROWB],
-                            &smem[buf][1][(wn * 64 + (lane & 31)) * ROWB], lane, acc);
+            mma_swz<T, TM>(&smem[buf][0], &smem[buf][ABYTES], arow, brow, lane, acc);
             if (more) CONV_LSTORE(buf ^ 1);
             __syncthreads();
         }
@@ -193,37 +298,30 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
 #undef CONV_GLOAD
 #undef CONV_LSTORE
 
-    // ---- epilogue ----
-    T* outT = reinterpret_cast<T*>(p.out);
-    float* outF = reinterpret_cast<float*>(p.out);
-    const T* resT = reinterpret_cast<const T*>(p.res);
-    const T* maskT = reinterpret_cast<const T*>(p.mask);
+    // ---- epilogue: accumulators -> LDS (per wave, 32 rows x 64 columns at a time) -> 8-column vectors.
+    // Going through LDS keeps the register->LDS part trivially unrollable (a large branchy epilogue
+    // indexed by acc[][][r] is NOT fully unrolled by hipcc and then parks all accumulators in scratch,
+    // 6x slower) and turns the global stores into coalesced 16/32-byte vectors.
+    float* ep = reinterpret_cast<float*>(&smem[0][0]) + wave * (32 * 64);
+    const int ecol = (lane & 7) * 8, erow = lane >> 3;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wn * 64 + tn * 32 + (lane & 31);
-            if (col >= p.Cout) continue;
-            const float bias = (!p.ws && p.bias) ? p.bias[col] : 0.f;
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[tm][tn][r];
-                if (p.ws) {
-                    p.ws[((size_t)z * p.M + row) * p.Cout + col] = v;
-                } else {
-                    v += bias;
-                    if (resT) v += ldf(resT + (size_t)row * p.ldres + col);
-                    if (p.act == DVD_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == DVD_ACT_TANH) v = tanhf(v);
-                    else if (p.act == DVD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                    if (maskT && !(ldf(maskT + (size_t)row * p.ldmask + col) > 0.f)) v = 0.f;
-                    if (p.out_f32) outF[(size_t)row * p.ldo + col] = v;
-                    else stf(outT + (size_t)row * p.ldo + col, v);
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes landed
+        __builtin_amdgcn_wave_barrier();
+        const int rbase = m0 + wm * (TM * 32) + tm * 32;
+        const int col = n0 + wn * 64 + ecol;
+        for (int j = 0; j < 4; ++j) {
+            const int row = rbase + j * 8 + erow;
+            if (row < p.M && col < p.Cout)
+                conv_store8<T>(p, ep + (j * 8 + erow) * 64 + ecol, row, col, z);
         }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ============================================================================ backward-weight
@@ -534,12 +632,19 @@ extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) {
     if (p.nsplit != (d->nsplit < 1 ? 1 : d->nsplit)) return DVD_E_ARG;   // caller sized ws for d->nsplit slabs
     p.tilesN = (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
-    dim3 grid(cdiv(M, BM) * p.tilesN, 1, p.nsplit);
+    // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
+    const bool big = cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= 512;   // >= 2 workgroups per CU
+    dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
-    if (d->dtype == DVD_BF16) conv_igemm_kernel<bf16_t><<<grid, NT, 0, (hipStream_t)stream>>>(p);
-    else if (d->dtype == DVD_F32) conv_igemm_kernel<float><<<grid, NT, 0, (hipStream_t)stream>>>(p);
-    else return DVD_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == DVD_BF16) {
+        if (big) conv_igemm_kernel<bf16_t, 4><<<grid, NT, 0, st>>>(p);
+        else conv_igemm_kernel<bf16_t, 2><<<grid, NT, 0, st>>>(p);
+    } else if (d->dtype == DVD_F32) {
+        if (big) conv_igemm_kernel<float, 4><<<grid, NT, 0, st>>>(p);
+        else conv_igemm_kernel<float, 2><<<grid, NT, 0, st>>>(p);
+    } else return DVD_E_ARG;
     return launch_status();
 }
 

@@ -1,0 +1,59 @@
+"""Times single conv_igemm / conv_wgrad launches on representative C2 shapes (HIP events).
+usage: python tools/conv_microbench.py [fwd|wgrad|all] [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dvd_gan_amd import kern as K
+
+SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
+    (64, 32, 512, 256, 5, True),      # GRU#3 h-path, serial step
+    (64, 16, 1024, 512, 5, True),     # GRU#2 h-path
+    (64, 8, 512, 512, 5, True),       # GRU#1 h-path (split-K)
+    (3072, 32, 256, 384, 5, False),   # GRU#3 batched x-path
+    (3072, 16, 256, 256, 3, False),   # GResBlock 3x3
+    (3072, 32, 128, 128, 3, False),
+]
+
+
+def bench(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    dev, dt = "cuda", torch.bfloat16
+    for F_, S, Cin, Cout, k, slabs in SHAPES:
+        x = torch.randn(F_, S, S, Cin, device=dev).to(dt)
+        pk = K.PackedConv(dt, Cout, Cin, (k, k), dev).fill(torch.randn(Cout, Cin, k, k, device=dev) * 0.05)
+        M = F_ * S * S
+        fl = 2.0 * M * Cout * Cin * k * k
+        if what in ("fwd", "all"):
+            import ctypes as C
+            from dvd_gan_amd import lib as L
+            ns = L.lib().dvd_conv_pick_nsplit(L.BF16, C.c_longlong(M), Cout, Cin, k * k) if slabs else 1
+            ws = torch.empty(ns, M, Cout, device=dev) if slabs else None
+            out = None if slabs else torch.empty(F_, S, S, Cout, device=dev, dtype=dt)
+            ms = bench(lambda: K.conv_forward(x, pk.wf, (k, k), Cout, nsplit=ns, ws=ws, out=out), iters)
+            print(f"fwd   M={M:8d} C={Cin:5d} Cout={Cout:5d} k={k} split={ns:2d}: {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
+        if what in ("wgrad", "all") and not slabs:
+            dy = torch.randn(F_, S, S, Cout, device=dev).to(dt)
+            dw = torch.zeros(Cout, Cin, k, k, device=dev)
+            ms = bench(lambda: K.conv_wgrad(x, dy, dw, (k, k), Cout, Cin), max(2, iters // 3))
+            print(f"wgrad M={M:8d} C={Cin:5d} Cout={Cout:5d} k={k}          : {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
