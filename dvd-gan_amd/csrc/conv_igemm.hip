@@ -79,6 +79,8 @@ struct ConvK {
     int T, H, W, logH, logW, Hin, Win;
     int kt, kh, kw, kchunks, nk, nsplit, tilesN;
     int up2, relu_in, act, out_f32;
+    size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
+    int maxshift;                        // largest |tap shift| in rows
 };
 
 // LDS tile image: 64-byte rows (one K chunk), no padding; the 16-byte slot of a row is XOR-swizzled
@@ -211,8 +213,23 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
     }
     const int co0 = n0 + r0, co1 = n0 + r0 + 64;
     const bool cov0 = co0 < p.Cout, cov1 = co1 < p.Cout;
-    const size_t ldb = (size_t)p.ldi * esz;            // input row pitch in bytes
-    const size_t wrow0 = ((size_t)co0 * p.C + q * E16) * esz, wrow1 = ((size_t)co1 * p.C + q * E16) * esz;
+    // Tile loads are buffer loads: a 32-bit byte offset per lane on top of a wave-uniform descriptor,
+    // and rows outside the frame / channels past C get offset 0xFFFFFFFF, which the hardware range
+    // check turns into zeros -- no 64-bit address math, no select masks, no divergent branches
+    // (a load inside a branch makes hipcc drain vmcnt(0) right there).
+    // Offsets are 32-bit, activations can exceed 4 GiB: the descriptor of the activation tensor starts
+    // at the first input row this tile can touch (wave-uniform), offsets are relative to it.
+    const unsigned ldb = (unsigned)p.ldi * (unsigned)esz;        // input row pitch in bytes
+    const int base_row = p.up2 ? (m0 >> (p.logW + p.logH)) * p.Hin * p.Win : max(0, m0 - p.maxshift);
+    const size_t base_b = (size_t)base_row * ldb;
+    const size_t left_b = p.in_bytes - base_b;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.in + base_b), 0, left_b > 0xfffffffeull ? 0xfffffffeu : (unsigned)left_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    unsigned aoff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) aoff[i] = (unsigned)(am[i] - base_row) * ldb + q * 16;
+    const unsigned woff0 = ((unsigned)co0 * p.C + q * E16) * (unsigned)esz, woff1 = ((unsigned)co1 * p.C + q * E16) * (unsigned)esz;
     // wave-uniform K-step state (tap decomposition kept incrementally)
     int tap = 0, cc = 0, it = 0, iy = 0, ix = 0;
     if (k_begin < k_end) {
@@ -220,54 +237,38 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
         it = tap / (p.kh * p.kw); const int rem = tap - it * p.kh * p.kw;
         iy = rem / p.kw; ix = rem - iy * p.kw;
     }
-    // Loads are issued UNCONDITIONALLY from a clamped (always valid) address and masked when they
-    // are written to LDS: a load inside a divergent branch makes hipcc drain vmcnt(0) right there,
-    // which serialises the loads of a K step and keeps them from overlapping the MFMAs.
     u32x4 ra[NA], rb0, rb1;
-    bool oa[NA], ob0 = false, ob1 = false;
     auto gload = [&]() __attribute__((always_inline)) {
         const int dt_ = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx_ = ix - (p.kw >> 1);
-        const int c_ = cc * BK + q * E16;
-        const bool cv_ = c_ < p.C;
-        // wave-uniform part of the address: tap shift + channel chunk (the per-lane slot q is in c_)
-        const long long delta_ = ((long long)(dt_ * p.H + dy_) * p.W + dx_) * (long long)ldb + (long long)c_ * (long long)esz;
-        const char* abase_ = p.in + delta_;
+        const bool cv_ = cc * BK + q * E16 < p.C;
+        // wave-uniform part of the offset: tap shift + channel chunk
+        const unsigned udelta_ = (unsigned)(((dt_ * p.H + dy_) * p.W + dx_) * (int)ldb + cc * 64);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_, tt_ = at[i] + dt_;
             const bool ok_ = av[i] && cv_ && (unsigned)yy_ < (unsigned)p.H && (unsigned)xx_ < (unsigned)p.W &&
                              (unsigned)tt_ < (unsigned)p.T;
-            const char* ptr_;
+            unsigned off_ = aoff[i] + udelta_;
             if (p.up2) {
                 const int f_ = am[i] >> (p.logW + p.logH);
-                const int row_ = ((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1);
-                ptr_ = p.in + (size_t)(unsigned)(ok_ ? row_ : 0) * ldb + (size_t)(ok_ ? c_ : 0) * esz;
-            } else {
-                ptr_ = abase_ + (size_t)(unsigned)am[i] * ldb;
-                ptr_ = ok_ ? ptr_ : p.in;
+                off_ = (unsigned)(((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1) - base_row) * ldb + cc * 64 + q * 16;
             }
-            ra[i] = *reinterpret_cast<const u32x4*>(ptr_);
-            oa[i] = ok_;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok_ ? off_ : 0xffffffffu, 0, 0);
         }
-        const char* wbase_ = p.w + ((size_t)tap * p.Cout * p.C + (size_t)cc * BK) * esz;
-        ob0 = cov0 && cv_; ob1 = cov1 && cv_;
-        rb0 = *reinterpret_cast<const u32x4*>(ob0 ? wbase_ + wrow0 : p.w);
-        rb1 = *reinterpret_cast<const u32x4*>(ob1 ? wbase_ + wrow1 : p.w);
+        const unsigned uw_ = (unsigned)(tap * p.Cout) * (unsigned)p.C * (unsigned)esz + cc * 64;
+        rb0 = __builtin_amdgcn_raw_buffer_load_b128(rw, (cov0 && cv_) ? woff0 + uw_ : 0xffffffffu, 0, 0);
+        rb1 = __builtin_amdgcn_raw_buffer_load_b128(rw, (cov1 && cv_) ? woff1 + uw_ : 0xffffffffu, 0, 0);
         if (++cc == p.kchunks) {
             cc = 0; ++tap;
             if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
         }
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
-        const u32x4 zero_ = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            u32x4 v_ = p.relu_in ? relu16<T>(ra[i]) : ra[i];
-            v_ = oa[i] ? v_ : zero_;
-            *reinterpret_cast<u32x4*>(&smem[buf][lds_off(r0 + 64 * i, q)]) = v_;
-        }
-        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0, q)]) = ob0 ? rb0 : zero_;
-        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0 + 64, q)]) = ob1 ? rb1 : zero_;
+        for (int i = 0; i < NA; ++i)
+            *reinterpret_cast<u32x4*>(&smem[buf][lds_off(r0 + 64 * i, q)]) = p.relu_in ? relu16<T>(ra[i]) : ra[i];
+        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0, q)]) = rb0;
+        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0 + 64, q)]) = rb1;
     };
 #define CONV_GLOAD() gload()
 #define CONV_LSTORE(buf) lstore(buf)
@@ -332,6 +333,8 @@ struct WgK {
     int kt, kh, kw, up2, relu_in;
     int tiles_co, tiles_ci, rows_per_split;
     long long s_co, s_ci, s_tap;
+    size_t x_bytes, dy_bytes;
+    int maxshift;
 };
 
 // D[co][ci] = sum over rows m of dy[m][co] * x[pos(m)+tap][ci].  The reduction index (rows) is the
@@ -339,41 +342,62 @@ struct WgK {
 //   bf16: tiles are staged in their natural [row][channel] image with 16-byte loads and the
 //         fragments are built by the LDS transpose read ds_read_b64_tr_b16;
 //   f32 : the natural [row][channel] image already matches the 32x32x2 fragment (1 float/lane).
-template <typename T>
+template <typename T, int TA, int TB>      // wave tile (TA*32 out-channels) x (TB*32 in-channels); block = 2 x 2 waves
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
     constexpr bool kBf16 = sizeof(T) == 2;
+    static_assert(kBf16 || (TA == 2 && TB == 2), "exact mode uses the 128 x 128 tile");
     constexpr int BKW = kBf16 ? 32 : 16;            // rows reduced per step
-    __shared__ __attribute__((aligned(16))) char smem[2][2][TILEB];
+    constexpr int BMc = TA * 64, BNc = TB * 64;     // block tile: out-channels x in-channels
+    constexpr int RSA = BMc * 2 + 64, RSB = BNc * 2 + 64;          // bf16 LDS row strides (bytes)
+    constexpr int TA_BYTES = kBf16 ? 32 * RSA : TILEB, TB_BYTES = kBf16 ? 32 * RSB : TILEB;
+    __shared__ __attribute__((aligned(16))) char smem[2][TA_BYTES + TB_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles = p.tiles_co * p.tiles_ci;
     const int tap = blockIdx.x / tiles;
     const int rem = blockIdx.x - tap * tiles;
     const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
-    const int co0 = tco * BM, ci0 = tci * BN;
+    const int co0 = tco * BMc, ci0 = tci * BNc;
     const int it = tap / (p.kh * p.kw), r2 = tap - it * p.kh * p.kw;
     const int iy = r2 / p.kw, ix = r2 - iy * p.kw;
     const int dt = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx = ix - (p.kw >> 1);
     const int m_begin = blockIdx.z * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TA][TB];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int b = 0; b < TB; ++b) acc[a][b] = zacc;
+    }
 
-    // shifted-row address of x for output row m (branch-free; `ok` false outside the frame)
-    auto xoff = [&](int m, bool& ok) -> size_t {
-        int xx = (m & (p.W - 1)) + dx, yy = ((m >> p.logW) & (p.H - 1)) + dy_;
-        const int f = m >> (p.logW + p.logH);
-        const int tt = (p.kt > 1 ? f % p.T : 0) + dt;
-        ok = m < m_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && (unsigned)tt < (unsigned)p.T;
-        if (p.up2) { yy >>= 1; xx >>= 1; }
-        const size_t o = (((size_t)(f + dt) * p.Hin + yy) * p.Win + xx) * (size_t)p.ldx;
-        return ok ? o : 0;
+    // Buffer descriptors: invalid rows / channels use offset 0xFFFFFFFF -> hardware returns zeros.
+    // (32-bit offsets relative to the first row this workgroup's row slice can touch: tensors > 4 GiB ok)
+    constexpr unsigned ESZ = sizeof(T);
+    const int xbase_row = p.up2 ? (m_begin >> (p.logW + p.logH)) * p.Hin * p.Win : max(0, m_begin - p.maxshift);
+    const size_t xbase_b = (size_t)xbase_row * p.ldx * ESZ, ybase_b = (size_t)m_begin * p.ldy * ESZ;
+    const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + xbase_b), 0, xleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)xleft, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ybase_b), 0, yleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)yleft, 0x00020000);
+    // Byte offset of the shifted x row for output row m.  Without upsampling the input grid equals
+    // the output grid, so the shifted row is simply m + delta.
+    const int delta = (dt * p.H + dy_) * p.W + dx;
+    auto xoff = [&](int m, unsigned chan_bytes, bool cvalid) __attribute__((always_inline)) -> unsigned {
+        const int xx = (m & (p.W - 1)) + dx, yy = ((m >> p.logW) & (p.H - 1)) + dy_;
+        int tt = dt;
+        if (p.kt > 1) tt += (m >> (p.logW + p.logH)) % p.T;
+        const bool ok = cvalid && m < m_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W &&
+                        (unsigned)tt < (unsigned)p.T;
+        int row = m + delta;
+        if (p.up2) row = (((m >> (p.logW + p.logH)) + dt) * p.Hin + (yy >> 1)) * p.Win + (xx >> 1);
+        return ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * ESZ) + chan_bytes : 0xffffffffu;
+    };
+    auto yoff = [&](int m, unsigned chan_bytes, bool cvalid) __attribute__((always_inline)) -> unsigned {
+        return (cvalid && m < m_end) ? (unsigned)(m - m_begin) * ((unsigned)p.ldy * ESZ) + chan_bytes : 0xffffffffu;
     };
 
     if constexpr (kBf16) {
@@ -381,57 +405,60 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
         // rows a 16-lane group touches land on disjoint bank quarters).  MFMA fragments need 8
         // consecutive ROWS of one channel per lane: ds_read_b64_tr_b16 delivers exactly that
         // (each 16-lane group reads a 4-row x 16-channel block and hands lane i column i).
-        constexpr int RS = 320;
-        const int rr = tid >> 4, chk = tid & 15;          // staged rows rr, rr+16; 16-byte chunk chk
-        const int cy = co0 + chk * 8, cx = ci0 + chk * 8;
+        // operand A = dy (BMc channels per row), operand B = x (BNc channels per row)
+        constexpr int CPRA = BMc / 8, RPPA = NT / CPRA, NPA = 32 / RPPA;       // chunks/row, rows/pass, passes
+        constexpr int CPRB = BNc / 8, RPPB = NT / CPRB, NPB = 32 / RPPB;
+        const int rra = tid / CPRA, cka = tid % CPRA, rrb = tid / CPRB, ckb = tid % CPRB;
+        const int cy = co0 + cka * 8, cx = ci0 + ckb * 8;
         const bool cyv = cy < p.Cy, cxv = cx < p.C;
-        u32x4 a0, a1, b0, b1;
-        bool oa0 = false, oa1 = false, ob0 = false, ob1 = false;
-#define WG_GLOAD(mk)                                                                              \
-    do {                                                                                          \
-        const int m0_ = (mk) + rr, m1_ = (mk) + rr + 16;                                          \
-        oa0 = cyv && m0_ < m_end; oa1 = cyv && m1_ < m_end;                                       \
-        const size_t oy0_ = oa0 ? ((size_t)m0_ * p.ldy + cy) : 0, oy1_ = oa1 ? ((size_t)m1_ * p.ldy + cy) : 0; \
-        a0 = *reinterpret_cast<const u32x4*>(p.dy + oy0_ * 2);                                     \
-        a1 = *reinterpret_cast<const u32x4*>(p.dy + oy1_ * 2);                                     \
-        size_t ox0_ = xoff(m0_, ob0), ox1_ = xoff(m1_, ob1);                                       \
-        ob0 = ob0 && cxv; ob1 = ob1 && cxv;                                                        \
-        ox0_ = ob0 ? ox0_ + cx : 0; ox1_ = ob1 ? ox1_ + cx : 0;                                    \
-        b0 = *reinterpret_cast<const u32x4*>(p.x + ox0_ * 2);                                      \
-        b1 = *reinterpret_cast<const u32x4*>(p.x + ox1_ * 2);                                      \
-    } while (0)
-#define WG_LSTORE(buf)                                                                            \
-    do {                                                                                          \
-        const u32x4 zero_ = {0u, 0u, 0u, 0u};                                                     \
-        u32x4 vb0_ = p.relu_in ? relu16_bf16(b0) : b0, vb1_ = p.relu_in ? relu16_bf16(b1) : b1;   \
-        *reinterpret_cast<u32x4*>(&smem[buf][0][rr * RS + chk * 16]) = oa0 ? a0 : zero_;           \
-        *reinterpret_cast<u32x4*>(&smem[buf][0][(rr + 16) * RS + chk * 16]) = oa1 ? a1 : zero_;    \
-        *reinterpret_cast<u32x4*>(&smem[buf][1][rr * RS + chk * 16]) = ob0 ? vb0_ : zero_;         \
-        *reinterpret_cast<u32x4*>(&smem[buf][1][(rr + 16) * RS + chk * 16]) = ob1 ? vb1_ : zero_;  \
-    } while (0)
-        // per-lane byte offset of its chunk inside a 4-row x 16-channel block of the fragment
+        u32x4 ra[NPA], rb[NPB];
+        auto wg_gload = [&](int mk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i)
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, yoff(mk + rra + i * RPPA, cy * 2, cyv), 0, 0);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + rrb + i * RPPB, cx * 2, cxv), 0, 0);
+        };
+        auto wg_lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i)
+                *reinterpret_cast<u32x4*>(&smem[buf][(rra + i * RPPA) * RSA + cka * 16]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+                *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + (rrb + i * RPPB) * RSB + ckb * 16]) =
+                    p.relu_in ? relu16_bf16(rb[i]) : rb[i];
+        };
+#define WG_GLOAD(mk) wg_gload(mk)
+#define WG_LSTORE(buf) wg_lstore(buf)
+        // per-lane offset of its 8-byte chunk inside a 4-row x 16-channel block of a fragment:
+        // rows (g16>>1)*8 + (i16>>2), channels (g16&1)*16 + (i16&3)*4
         const int g16 = lane >> 4, i16 = lane & 15;
-        const int frag_off = ((g16 >> 1) * 8 + (i16 >> 2)) * RS + ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;
-        auto frag = [&](const char* tile, int col0, int kb) -> bf16x8 {
+        const int frow = (g16 >> 1) * 8 + (i16 >> 2), fcol2 = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;
+        auto frag = [&](const char* tile, int rs, int col0, int kb) __attribute__((always_inline)) -> bf16x8 {
             typedef __attribute__((ext_vector_type(4))) short s16x4;
             typedef __attribute__((ext_vector_type(8))) short s16x8;
-            const char* pz = tile + frag_off + kb * RS + col0 * 2;
+            const char* pz = tile + (frow + kb) * rs + fcol2 + col0 * 2;
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pz);
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pz + 4 * RS));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pz + 4 * rs));
             s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return __builtin_bit_cast(bf16x8, f);
         };
-        auto mma = [&](int buf) {
-            const char* At = &smem[buf][0][0];
-            const char* Bt = &smem[buf][1][0];
+        auto mma = [&](int buf) __attribute__((always_inline)) {
+            const char* At = &smem[buf][0];
+            const char* Bt = &smem[buf][TA_BYTES];
 #pragma unroll
             for (int kb = 0; kb < 32; kb += 16) {
-                const bf16x8 fa0 = frag(At, wm * 64, kb), fa1 = frag(At, wm * 64 + 32, kb);
-                const bf16x8 fb0 = frag(Bt, wn * 64, kb), fb1 = frag(Bt, wn * 64 + 32, kb);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+                bf16x8 fa[TA], fb[TB];
+#pragma unroll
+                for (int a = 0; a < TA; ++a) fa[a] = frag(At, RSA, wm * (TA * 32) + a * 32, kb);
+#pragma unroll
+                for (int b = 0; b < TB; ++b) fb[b] = frag(Bt, RSB, wn * (TB * 32) + b * 32, kb);
+#pragma unroll
+                for (int a = 0; a < TA; ++a)
+#pragma unroll
+                    for (int b = 0; b < TB; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
             }
         };
         if (m_begin < m_end) {
@@ -455,30 +482,21 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
         const int cy = co0 + ch * 4, cx = ci0 + ch * 4;
         const bool cyv = cy < p.Cy, cxv = cx < p.C;
         u32x4 a0, a1, b0, b1;
-        bool oa0 = false, oa1 = false, ob0 = false, ob1 = false;
-        auto gload = [&](int mk) {
-            const int m0_ = mk + kr, m1_ = mk + kr + 8;
-            oa0 = cyv && m0_ < m_end; oa1 = cyv && m1_ < m_end;
-            const size_t oy0 = oa0 ? ((size_t)m0_ * p.ldy + cy) : 0, oy1 = oa1 ? ((size_t)m1_ * p.ldy + cy) : 0;
-            a0 = *reinterpret_cast<const u32x4*>(p.dy + oy0 * 4);
-            a1 = *reinterpret_cast<const u32x4*>(p.dy + oy1 * 4);
-            size_t ox0 = xoff(m0_, ob0), ox1 = xoff(m1_, ob1);
-            ob0 = ob0 && cxv; ob1 = ob1 && cxv;
-            ox0 = ob0 ? ox0 + cx : 0; ox1 = ob1 ? ox1 + cx : 0;
-            b0 = *reinterpret_cast<const u32x4*>(p.x + ox0 * 4);
-            b1 = *reinterpret_cast<const u32x4*>(p.x + ox1 * 4);
+        auto gload = [&](int mk) __attribute__((always_inline)) {
+            a0 = __builtin_amdgcn_raw_buffer_load_b128(rdy, yoff(mk + kr, cy * 4, cyv), 0, 0);
+            a1 = __builtin_amdgcn_raw_buffer_load_b128(rdy, yoff(mk + kr + 8, cy * 4, cyv), 0, 0);
+            b0 = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + kr, cx * 4, cxv), 0, 0);
+            b1 = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + kr + 8, cx * 4, cxv), 0, 0);
         };
-        auto lstore = [&](int buf) {
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-            const u32x4 vb0 = p.relu_in ? relu16_f32(b0) : b0, vb1 = p.relu_in ? relu16_f32(b1) : b1;
-            *reinterpret_cast<u32x4*>(&smem[buf][0][(kr * WG_LD + ch * 4) * 4]) = oa0 ? a0 : zero;
-            *reinterpret_cast<u32x4*>(&smem[buf][0][((kr + 8) * WG_LD + ch * 4) * 4]) = oa1 ? a1 : zero;
-            *reinterpret_cast<u32x4*>(&smem[buf][1][(kr * WG_LD + ch * 4) * 4]) = ob0 ? vb0 : zero;
-            *reinterpret_cast<u32x4*>(&smem[buf][1][((kr + 8) * WG_LD + ch * 4) * 4]) = ob1 ? vb1 : zero;
+        auto lstore = [&](int buf) __attribute__((always_inline)) {
+            *reinterpret_cast<u32x4*>(&smem[buf][(kr * WG_LD + ch * 4) * 4]) = a0;
+            *reinterpret_cast<u32x4*>(&smem[buf][((kr + 8) * WG_LD + ch * 4) * 4]) = a1;
+            *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + (kr * WG_LD + ch * 4) * 4]) = p.relu_in ? relu16_f32(b0) : b0;
+            *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + ((kr + 8) * WG_LD + ch * 4) * 4]) = p.relu_in ? relu16_f32(b1) : b1;
         };
         auto mma = [&](int buf) {
-            const float* As = reinterpret_cast<const float*>(&smem[buf][0][0]) + wm * 64 + (lane & 31);
-            const float* Bs = reinterpret_cast<const float*>(&smem[buf][1][0]) + wn * 64 + (lane & 31);
+            const float* As = reinterpret_cast<const float*>(&smem[buf][0]) + wm * 64 + (lane & 31);
+            const float* Bs = reinterpret_cast<const float*>(&smem[buf][TA_BYTES]) + wn * 64 + (lane & 31);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const int k = kk * 2 + (lane >> 5);
@@ -505,19 +523,30 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
         }
     }
 
+    // epilogue: each 32x32 accumulator tile goes through a per-wave LDS block and is then added to
+    // dw with a rolled loop (an unrolled 128-atomic epilogue costs ~170 VGPRs of addresses)
+    float* ep = reinterpret_cast<float*>(&smem[0][0]) + wave * (32 * 32);
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int ci = ci0 + wn * 64 + tn * 32 + (lane & 31);
-            if (ci >= p.Cin_real) continue;
+        for (int tb = 0; tb < TB; ++tb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co >= p.Cout) continue;
-                const float v = acc[tm][tn][r];
-                if (v != 0.f) atomicAdd(p.dw + co * p.s_co + ci * p.s_ci + tap * p.s_tap, v);
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[ta][tb][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int ci = ci0 + wn * (TB * 32) + tb * 32 + (lane & 31);
+            const int cob = co0 + wm * (TA * 32) + ta * 32 + (lane >> 5);
+            float* dst = p.dw + ci * p.s_ci + tap * p.s_tap;
+            if (ci < p.Cin_real) {
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j) {
+                    const int co = cob + 2 * j;
+                    const float v = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+                    if (co < p.Cout && v != 0.f) atomicAdd(dst + co * p.s_co, v);
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
 }
 
@@ -632,6 +661,15 @@ extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) {
     if (p.nsplit != (d->nsplit < 1 ? 1 : d->nsplit)) return DVD_E_ARG;   // caller sized ws for d->nsplit slabs
     p.tilesN = (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
+    {   // extents of the two buffer descriptors (32-bit byte offsets): tensors must stay below 4 GiB
+        const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
+        const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;
+        const size_t inb = ((rows_in - 1) * (size_t)d->ldi + d->C) * esz;
+        const size_t wb = (size_t)d->kt * d->kh * d->kw * d->Cout * d->C * esz;
+        if (wb >= 0xffffffffull) return DVD_E_SHAPE;
+        p.in_bytes = inb; p.w_bytes = (unsigned)wb;
+        p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
+    }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     const bool big = cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= 512;   // >= 2 workgroups per CU
     dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
@@ -662,8 +700,22 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     p.T = d->T; p.H = d->H; p.W = d->W; p.logH = logH; p.logW = logW;
     p.Hin = d->up2 ? d->H / 2 : d->H; p.Win = d->up2 ? d->W / 2 : d->W;
     p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.up2 = d->up2; p.relu_in = d->relu_in;
-    p.tiles_co = (d->Cout + BM - 1) / BM; p.tiles_ci = (d->Cin_real + BN - 1) / BN;
+    // bf16: 256-wide tile along whichever channel axis is long enough (2x the MFMAs per barrier)
+    int ta = 2, tb = 2;
+    if (d->dtype == DVD_BF16) {
+        if (d->Cout >= 192) ta = 4;
+        else if (d->Cin_real >= 192) tb = 4;
+    }
+    p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap;
+    {
+        const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
+        const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;
+        const size_t xb = ((rows_in - 1) * (size_t)d->ldx + d->C) * esz;
+        const size_t yb = (((size_t)M - 1) * (size_t)d->ldy + d->Cy) * esz;
+        p.x_bytes = xb; p.dy_bytes = yb;
+        p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
+    }
     const int ntaps = d->kt * d->kh * d->kw;
     long long msplit = d->msplit;
     if (msplit < 1) {   // auto: enough workgroups to fill 256 CUs a few times over
@@ -671,6 +723,11 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
         msplit = (1024 + base - 1) / base;
     }
     long long rows = (M + msplit - 1) / msplit;
+    {   // a workgroup's row slice is addressed with 32-bit byte offsets
+        const long long ldmax = (d->ldx > d->ldy ? d->ldx : d->ldy) * (d->dtype == DVD_BF16 ? 2ll : 4ll);
+        const long long cap = (1ll << 31) / ldmax;
+        if (rows > cap) rows = cap;
+    }
     rows = (rows + 31) / 32 * 32;
     if (rows < 32) rows = 32;
     msplit = (M + rows - 1) / rows;
@@ -678,8 +735,12 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     dim3 grid(p.tiles_co * p.tiles_ci * ntaps, 1, (unsigned)msplit);
     ProfScope prof(1, 2.0 * (double)M * d->Cout * d->Cin_real * ntaps, stream, M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
-    if (d->dtype == DVD_BF16) conv_wgrad_kernel<bf16_t><<<grid, NT, 0, (hipStream_t)stream>>>(p);
-    else if (d->dtype == DVD_F32) conv_wgrad_kernel<float><<<grid, NT, 0, (hipStream_t)stream>>>(p);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == DVD_BF16) {
+        if (ta == 4) conv_wgrad_kernel<bf16_t, 4, 2><<<grid, NT, 0, st>>>(p);
+        else if (tb == 4) conv_wgrad_kernel<bf16_t, 2, 4><<<grid, NT, 0, st>>>(p);
+        else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, NT, 0, st>>>(p);
+    } else if (d->dtype == DVD_F32) conv_wgrad_kernel<float, 2, 2><<<grid, NT, 0, st>>>(p);
     else return DVD_E_ARG;
     return launch_status();
 }
