@@ -78,6 +78,19 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// value a T-typed store would keep (bf16 rounding; identity for fp32)
+template <typename T> __device__ __forceinline__ float round_to(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// Internal (not part of the public ABI): ConvGRU gate math fused into the convolution epilogue, used
+// by gru.hip when the recurrent conv needs no split-K.  mode 1: [u|r] conv, mode 2: out-gate conv.
+struct GruEpi {
+    int mode, h, ldg;
+    const void* gx; const void* hprev; const float* h32p; const void* u_in;
+    void* u; void* r; void* hr; void* o; void* hn; float* h32n;
+};
+extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream);
+
 static inline int ilog2_exact(int v) {   // host: log2 of a power of two, -1 otherwise
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

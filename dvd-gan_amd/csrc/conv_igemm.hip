@@ -81,6 +81,7 @@ struct ConvK {
     int up2, relu_in, act, out_f32;
     size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
     int maxshift;                        // largest |tap shift| in rows
+    GruEpi g;                            // optional fused ConvGRU gate epilogue (mode 0 = off)
 };
 
 // LDS tile image: 64-byte rows (one K chunk), no padding; the 16-byte slot of a row is XOR-swizzled
@@ -137,6 +138,43 @@ __device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, in
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = src[k];
     const int nvalid = min(8, p.Cout - col);
+    if (p.g.mode == 1) {            // [u|r] = sigmoid(acc + gx);  hr = h_prev * r        (ConvGRU.py:47-49)
+        const int h = p.g.h;
+        float gxv[8];
+        load8<T>(reinterpret_cast<const T*>(p.g.gx) + (size_t)row * p.g.ldg + col, gxv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 1.f / (1.f + expf(-(v[k] + gxv[k])));
+        if (col < h) {
+            store8<T>(reinterpret_cast<T*>(p.g.u) + (size_t)row * h + col, v);
+        } else {
+            const size_t o = (size_t)row * h + (col - h);
+            float hp[8];
+            load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = round_to<T>(v[k]); hp[k] *= v[k]; }
+            store8<T>(reinterpret_cast<T*>(p.g.r) + o, v);
+            store8<T>(reinterpret_cast<T*>(p.g.hr) + o, hp);
+        }
+        return;
+    }
+    if (p.g.mode == 2) {            // o = tanh(acc + gx_o);  h = h_prev (1 - u) + o u          (ConvGRU.py:50-52)
+        const int h = p.g.h;
+        const size_t o = (size_t)row * h + col;
+        float gxv[8], hp[8], uu[8];
+        load8<T>(reinterpret_cast<const T*>(p.g.gx) + (size_t)row * p.g.ldg + 2 * h + col, gxv);
+        if (p.g.h32p) load8<float>(p.g.h32p + o, hp);
+        else load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
+        load8<T>(reinterpret_cast<const T*>(p.g.u_in) + o, uu);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = round_to<T>(tanhf(v[k] + gxv[k]));
+            hp[k] = hp[k] * (1.f - uu[k]) + v[k] * uu[k];
+        }
+        store8<T>(reinterpret_cast<T*>(p.g.o) + o, v);
+        store8<T>(reinterpret_cast<T*>(p.g.hn) + o, hp);
+        if (p.g.h32n) store8<float>(p.g.h32n + o, hp);
+        return;
+    }
     if (p.ws) {                                                    // raw split-K partial sums
         float* dst = p.ws + ((size_t)z * p.M + row) * p.Cout + col;
         if (nvalid == 8 && !(p.Cout & 3)) {
@@ -636,8 +674,11 @@ extern "C" long long dvd_prof_report(int kind, double* total_ms, double* total_f
 }
 
 // ============================================================================ C ABI
-extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) {
+extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) { return dvd_conv_forward_gru(d, nullptr, stream); }
+
+extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream) {
     if (!d || !d->in || !d->w || (!d->ws && (!d->out || d->nsplit > 1))) return DVD_E_ARG;
+    if (g && (d->ws || d->nsplit > 1 || (g->h & 7))) return DVD_E_ARG;
     if (d->frames <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Cout <= 0) return DVD_E_ARG;
     const int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
     if (logH < 0 || logW < 0) return DVD_E_SHAPE;
@@ -661,6 +702,7 @@ extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) {
     if (p.nsplit != (d->nsplit < 1 ? 1 : d->nsplit)) return DVD_E_ARG;   // caller sized ws for d->nsplit slabs
     p.tilesN = (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
+    if (g) p.g = *g; else p.g = GruEpi{};
     {   // extents of the two buffer descriptors (32-bit byte offsets): tensors must stay below 4 GiB
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
         const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;

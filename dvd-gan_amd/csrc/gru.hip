@@ -19,8 +19,6 @@
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-template <typename T> __device__ __forceinline__ float round_to(float v) { return v; }
-template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
 // u, r, hr for one step.  ws: [ns][M][2h] fp32 partial sums of conv(h_prev; Wh_ur) (ns may be 0).
 template <typename T>
@@ -169,6 +167,15 @@ __global__ void gru_dh0_kernel(const float* carry, const float* ws, int ns, floa
     out[i] = v;
 }
 
+// recurrent conv whose epilogue applies the gate math directly (no split-K, no fp32 slabs)
+int conv_fused(int dtype, int B, int H, int W, int k, const void* in, int C, const void* w, int Cout, const GruEpi& g,
+               void* stream) {
+    dvd_conv_desc d = {};
+    d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = C; d.Cout = Cout; d.ldo = Cout;
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.out = g.mode == 1 ? g.u : g.o;
+    return dvd_conv_forward_gru(&d, &g, stream);
+}
+
 int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, int Cout,
                int nsplit, float* ws, void* stream) {
     dvd_conv_desc d = {};
@@ -220,21 +227,36 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
         const float* h32p = (d->h32 && t > 0) ? d->h32 + (size_t)(t & 1) * M * h : nullptr;
         float* h32n = d->h32 ? d->h32 + (size_t)((t + 1) & 1) * M * h : nullptr;
         int rc, ns = 0;
-        if (hprev) {
-            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hprev, h, h, d->w_ur, 2 * h, ns_ur, d->ws, stream);
+        GruEpi g = {};
+        g.h = h; g.ldg = 3 * h; g.gx = gx; g.hprev = hprev; g.h32p = h32p; g.u_in = u;
+        g.u = u; g.r = r; g.hr = hr; g.o = o; g.hn = hn; g.h32n = h32n;
+        if (hprev && ns_ur == 1) {           // enough output tiles: gates applied in the conv epilogue
+            g.mode = 1;
+            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hprev, h, d->w_ur, 2 * h, g, stream);
             if (rc) return rc;
-            ns = ns_ur;
+        } else {
+            if (hprev) {
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hprev, h, h, d->w_ur, 2 * h, ns_ur, d->ws, stream);
+                if (rc) return rc;
+                ns = ns_ur;
+            }
+            BY_DTYPE(d->dtype, gru_gates_ur_kernel<T><<<grid, 256, 0, S_>>>(d->ws, ns, (const T*)gx, 3 * h,
+                                                                            (const T*)hprev, (T*)u, (T*)r, (T*)hr, M, h));
         }
-        BY_DTYPE(d->dtype, gru_gates_ur_kernel<T><<<grid, 256, 0, S_>>>(d->ws, ns, (const T*)gx, 3 * h, (const T*)hprev,
-                                                                        (T*)u, (T*)r, (T*)hr, M, h));
         ns = 0;
-        if (hprev) {
-            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hr, h, h, d->w_o, h, ns_o, d->ws, stream);
+        if (hprev && ns_o == 1) {
+            g.mode = 2;
+            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hr, h, d->w_o, h, g, stream);
             if (rc) return rc;
-            ns = ns_o;
+        } else {
+            if (hprev) {
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hr, h, h, d->w_o, h, ns_o, d->ws, stream);
+                if (rc) return rc;
+                ns = ns_o;
+            }
+            BY_DTYPE(d->dtype, gru_out_kernel<T><<<grid, 256, 0, S_>>>(d->ws, ns, (const T*)gx, 3 * h, (const T*)hprev,
+                                                                       h32p, (const T*)u, (T*)o, (T*)hn, h32n, M, h));
         }
-        BY_DTYPE(d->dtype, gru_out_kernel<T><<<grid, 256, 0, S_>>>(d->ws, ns, (const T*)gx, 3 * h, (const T*)hprev, h32p,
-                                                                   (const T*)u, (T*)o, (T*)hn, h32n, M, h));
     }
     return launch_status();
 }

@@ -20,38 +20,38 @@ __device__ float block_sum(float v, float* sh) {          // blockDim.x <= 1024,
 // ----------------------------------------------------------------------------- spectral norm
 // Normalization.py:19-31 -- one power iteration on W [h][w]:
 //   v <- W^T u / (|W^T u| + eps);  u <- W v / (|W v| + eps);  sigma = u . (W v)
-// single workgroup (1024 threads); u, v updated in place, *sigma written.
-__global__ __launch_bounds__(1024) void sn_power_iter_kernel(const float* W, int h, int w, float* u, float* v,
-                                                             float* sigma, float eps) {
+// Three launches so that the two matrix-vector products use the whole chip (the largest matrix is
+// 512 x 4608 and there are 127 iterations per training step):
+//   1. v_raw = W^T u          (grid over column blocks x row chunks, fp32 atomics into v, pre-zeroed)
+//   2. t     = W v_raw        (one wave per row; written over u)
+//   3. n_v = |v_raw|+eps, v = v_raw/n_v, (W v) = t/n_v, n = |W v|, u = (W v)/(n+eps), sigma = n^2/(n+eps)
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* W, int h, int w, const float* u, float* v) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * 64, i1 = min(h, i0 + 64);
+    if (j >= w) return;
+    float a = 0.f;
+    for (int i = i0; i < i1; ++i) a += W[(size_t)i * w + j] * u[i];
+    atomicAdd(v + j, a);
+}
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* W, int h, int w, const float* v, float* t) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= h) return;
+    float a = 0.f;
+    for (int j = lane; j < w; j += 64) a += W[(size_t)i * w + j] * v[j];
+    a = wave_sum(a);
+    if (lane == 0) t[i] = a;
+}
+__global__ __launch_bounds__(1024) void sn_finish_kernel(int h, int w, float* u, float* v, float* sigma, float eps) {
     __shared__ float sh[32];
-    extern __shared__ float ush[];                 // h floats: u
-    for (int i = threadIdx.x; i < h; i += blockDim.x) ush[i] = u[i];
-    __syncthreads();
-    // phase 1: v_raw = W^T u (thread per column, coalesced along the row)
     float ss = 0.f;
-    for (int j = threadIdx.x; j < w; j += blockDim.x) {
-        float a = 0.f;
-        for (int i = 0; i < h; ++i) a += W[(size_t)i * w + j] * ush[i];
-        v[j] = a;
-        ss += a * a;
-    }
+    for (int j = threadIdx.x; j < w; j += blockDim.x) ss += v[j] * v[j];
     const float nv = sqrtf(block_sum(ss, sh)) + eps;
     for (int j = threadIdx.x; j < w; j += blockDim.x) v[j] = v[j] / nv;
-    __syncthreads();
-    // phase 2: u_raw = W v (wave per row)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    for (int i = wave; i < h; i += nw) {
-        float a = 0.f;
-        for (int j = lane; j < w; j += 64) a += W[(size_t)i * w + j] * v[j];
-        a = wave_sum(a);
-        if (lane == 0) ush[i] = a;
-    }
-    __syncthreads();
     float s2 = 0.f;
-    for (int i = threadIdx.x; i < h; i += blockDim.x) s2 += ush[i] * ush[i];
+    for (int i = threadIdx.x; i < h; i += blockDim.x) { const float t = u[i] / nv; u[i] = t; s2 += t * t; }
     const float n2 = block_sum(s2, sh);
     const float nu = sqrtf(n2) + eps;
-    for (int i = threadIdx.x; i < h; i += blockDim.x) u[i] = ush[i] / nu;
+    for (int i = threadIdx.x; i < h; i += blockDim.x) u[i] = u[i] / nu;
     if (threadIdx.x == 0) *sigma = n2 / nu;        // u . (W v) = |W v|^2 / (|W v| + eps)
 }
 
@@ -235,8 +235,10 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
 
 extern "C" int dvd_sn_power_iter(const float* W, int h, int w, float* u, float* v, float* sigma, void* stream) {
     if (!W || !u || !v || !sigma || h <= 0 || w <= 0) return DVD_E_ARG;
-    if (h > 8192) return DVD_E_SHAPE;
-    sn_power_iter_kernel<<<1, 1024, h * sizeof(float), S_>>>(W, h, w, u, v, sigma, 1e-12f);
+    if (hipMemsetAsync(v, 0, (size_t)w * sizeof(float), S_) != hipSuccess) return DVD_E_LAUNCH;
+    sn_wtu_kernel<<<dim3(cdiv(w, 256), cdiv(h, 64)), 256, 0, S_>>>(W, h, w, u, v);
+    sn_wv_kernel<<<cdiv(h, 4), 256, 0, S_>>>(W, h, w, v, u);
+    sn_finish_kernel<<<1, 1024, 0, S_>>>(h, w, u, v, sigma, 1e-12f);
     return launch_status();
 }
 extern "C" int dvd_sn_backward(const float* G, const float* W, const float* u, const float* v, const float* sigma,

@@ -239,3 +239,34 @@ def test_temporal_discriminator(golden, dtype):
     check_param_grads(D, sub(g, "grad"), gt)
     with pytest.raises(RuntimeError):           # quirk 4, same as the reference
         D(torch.rand(1, 3, 8, 16, 16, device=DEV), cls[:1])
+
+
+# ------------------------------------------------------------------ fused-epilogue recurrent path
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_convgru_large_rows_uses_fused_gate_epilogue(dtype):
+    """With >= 256 output tiles the recurrent convs run without split-K and apply the gate math in
+    their epilogue (csrc/conv_igemm.hip conv_store8, GruEpi).  The small golden fixtures never reach
+    that path, so it is checked here against the CPU oracle: 3 steps, B=8, 64x64, hidden 64, k=3."""
+    import ctypes as C
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd import lib as L
+    from dvd_gan_amd.gen_net import ConvGRUCell
+    T, B, S, cin, hid, k = 3, 8, 64, 8, 64, 3
+    assert L.lib().dvd_conv_pick_nsplit(L.BF16, C.c_longlong(B * S * S), 2 * hid, hid, k * k) == 1
+    torch.manual_seed(11)
+    cell = ConvGRUCell(cin, hid, k)
+    for p in cell.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.1)
+    sd = O.make_state({kk: v.detach().clone() for kk, v in cell.state_dict().items()}, requires_grad=False)
+    xs = torch.randn(T, B, cin, S, S)
+    h, want = None, []
+    with torch.no_grad():
+        for i in range(T):
+            h = O.convgru_cell(sd, "", xs[i], h)
+            want.append(h)
+    want = torch.stack(want)
+    cell = cell.to(DEV)
+    with torch.no_grad():
+        got = ncl(cell.run(cl(xs.reshape(T * B, cin, S, S).to(DEV), dtype), T, False), hid).view(T, B, hid, S, S)
+    assert rel(got, want) < (1e-5 if dtype == torch.float32 else 1e-2)
