@@ -84,6 +84,13 @@ struct ConvK {
     GruEpi g;                            // optional fused ConvGRU gate epilogue (mode 0 = off)
 };
 
+// 16-byte-per-lane LDS-DMA: LDS[lds + lane*16 .. +16) <- buffer[off]; zeros when off is out of range.
+// `lds` must be wave-uniform.  (Kept in a non-template helper: inside a kernel template hipcc's HOST
+// pass rejects the target builtin as a silent substitution failure and drops the kernel stub.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, off, 0, 0, 0);
+}
+
 // LDS tile image: 64-byte rows (one K chunk), no padding; the 16-byte slot of a row is XOR-swizzled
 // with bits 2..3 of the row index.  Conflict-free for the loader's ds_write_b128 (8 consecutive lanes
 // = 2 rows x 4 slots = all 32 banks) and for the fragment ds_read_b128 (a 16-lane group reads 16 rows
@@ -92,7 +99,7 @@ struct ConvK {
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
 // acc[tm][tn] += A(TM*32 rows of this wave) x B(64 cols of this wave) over one 64-byte K chunk.
-template <typename T, int TM>
+template <typename T, int TM, bool RELU>
 __device__ __forceinline__ void mma_swz(const char* At, const char* Bt, int arow, int brow, int lane,
                                         f32x16 (&acc)[TM][2]) {
     const int kh = lane >> 5;
@@ -104,7 +111,13 @@ __device__ __forceinline__ void mma_swz(const char* At, const char* Bt, int arow
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) b[tn] = *reinterpret_cast<const bf16x8*>(Bt + lds_off(brow + tn * 32, slot));
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const bf16x8*>(At + lds_off(arow + tm * 32, slot));
+            for (int tm = 0; tm < TM; ++tm) {
+                u32x4 raw = *reinterpret_cast<const u32x4*>(At + lds_off(arow + tm * 32, slot));
+                // ReLU of the conv input (LDS-DMA cannot transform data) is applied on the fragment; it is a
+                // compile-time variant: a runtime branch here makes hipcc wait lgkmcnt(0) after every ds_read
+                if constexpr (RELU) raw = relu16_bf16(raw);
+                a[tm] = __builtin_bit_cast(bf16x8, raw);
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -120,8 +133,10 @@ __device__ __forceinline__ void mma_swz(const char* At, const char* Bt, int arow
             for (int tn = 0; tn < 2; ++tn)
                 b[tn] = *reinterpret_cast<const float*>(Bt + lds_off(brow + tn * 32, k >> 2) + (k & 3) * 4);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm) {
                 a[tm] = *reinterpret_cast<const float*>(At + lds_off(arow + tm * 32, k >> 2) + (k & 3) * 4);
+                if constexpr (RELU) a[tm] = fmaxf(a[tm], 0.f);
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -220,17 +235,25 @@ __device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, in
 // Workgroup = 2 x 2 waves, wave tile = (TM*32) x 64  =>  block tile BM = TM*64 rows x 128 columns.
 // TM = 4 (256 x 128) is the production shape: 16 MFMAs per wave between barriers and 6 instead of 8
 // fragment reads per 8 MFMAs; TM = 2 (128 x 128) serves problems with few rows.
-template <typename T, int TM>
+template <typename T, int TM, bool RELU>
 __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
     constexpr int E16 = ElemTraits<T>::kPer16B;
     constexpr int BK = 4 * E16;
     constexpr int BMt = TM * 64;
     constexpr int NA = BMt / 64;                       // activation rows staged per thread
     constexpr int ABYTES = BMt * 64, BBYTES = BN * 64;
-    __shared__ __attribute__((aligned(16))) char smem[2][ABYTES + BBYTES];
+    constexpr int NSTAGE = 3;                          // LDS ring: tile k is multiplied while k+1, k+2 are in flight
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE][ABYTES + BBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int mt = blockIdx.x / p.tilesN, nt = blockIdx.x - mt * p.tilesN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only);
+    // give each XCD a contiguous run of tiles so the N-tiles of one M-tile share that XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
+    }
+    const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
     const int m0 = mt * BMt, n0 = nt * BN;
     const int z = blockIdx.z;
     const int per = (p.nk + p.nsplit - 1) / p.nsplit;
@@ -238,23 +261,26 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
     const int k_end = min(p.nk, k_begin + per);
     const size_t esz = sizeof(T);
 
-    // ---- loader coordinates: this thread stages rows r0 + 64*i, 16-byte slot q ----
-    const int q = tid & 3, r0 = tid >> 2;
+    // ---- staging: LDS-DMA (buffer_load ... lds).  One wave-instruction moves 64 x 16 B = 16 tile rows
+    // straight from L2 into LDS (destination = wave-uniform base + lane*16, i.e. linear), so the tile
+    // never passes through VGPRs and no ds_write is issued.  The XOR swizzle of lds_off() is applied
+    // to the SOURCE: lane l lands on physical slot l&3 of row l>>2 and therefore fetches logical slot
+    // (l&3) ^ ((row>>2)&3).  Rows outside the frame / channels past C use offset 0xFFFFFFFF, for
+    // which the buffer range check stores zeros.  Wave w moves row groups w, w+4, ...
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int lrow = lane >> 2;                               // row inside a 16-row group
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);             // logical 16-byte slot this lane fetches
     int am[NA], ax[NA], ay[NA], at[NA];
     bool av[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + r0 + 64 * i;
+        const int m = m0 + (i * 4 + wu) * 16 + lrow;
         am[i] = m; av[i] = m < p.M;
         ax[i] = m & (p.W - 1); ay[i] = (m >> p.logW) & (p.H - 1);
         at[i] = p.kt > 1 ? (m >> (p.logW + p.logH)) % p.T : 0;
     }
-    const int co0 = n0 + r0, co1 = n0 + r0 + 64;
+    const int co0 = n0 + wu * 16 + lrow, co1 = n0 + (4 + wu) * 16 + lrow;
     const bool cov0 = co0 < p.Cout, cov1 = co1 < p.Cout;
-    // Tile loads are buffer loads: a 32-bit byte offset per lane on top of a wave-uniform descriptor,
-    // and rows outside the frame / channels past C get offset 0xFFFFFFFF, which the hardware range
-    // check turns into zeros -- no 64-bit address math, no select masks, no divergent branches
-    // (a load inside a branch makes hipcc drain vmcnt(0) right there).
     // Offsets are 32-bit, activations can exceed 4 GiB: the descriptor of the activation tensor starts
     // at the first input row this tile can touch (wave-uniform), offsets are relative to it.
     const unsigned ldb = (unsigned)p.ldi * (unsigned)esz;        // input row pitch in bytes
@@ -275,12 +301,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
         it = tap / (p.kh * p.kw); const int rem = tap - it * p.kh * p.kw;
         iy = rem / p.kw; ix = rem - iy * p.kw;
     }
-    u32x4 ra[NA], rb0, rb1;
-    auto gload = [&]() __attribute__((always_inline)) {
+    auto dma = [&](int buf) __attribute__((always_inline)) {
         const int dt_ = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx_ = ix - (p.kw >> 1);
         const bool cv_ = cc * BK + q * E16 < p.C;
         // wave-uniform part of the offset: tap shift + channel chunk
         const unsigned udelta_ = (unsigned)(((dt_ * p.H + dy_) * p.W + dx_) * (int)ldb + cc * 64);
+        char* abase_ = &smem[buf][wu * 1024];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_, tt_ = at[i] + dt_;
@@ -291,25 +317,17 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
                 const int f_ = am[i] >> (p.logW + p.logH);
                 off_ = (unsigned)(((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1) - base_row) * ldb + cc * 64 + q * 16;
             }
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok_ ? off_ : 0xffffffffu, 0, 0);
+            dma16(rin, abase_ + i * 4096, ok_ ? off_ : 0xffffffffu);
         }
         const unsigned uw_ = (unsigned)(tap * p.Cout) * (unsigned)p.C * (unsigned)esz + cc * 64;
-        rb0 = __builtin_amdgcn_raw_buffer_load_b128(rw, (cov0 && cv_) ? woff0 + uw_ : 0xffffffffu, 0, 0);
-        rb1 = __builtin_amdgcn_raw_buffer_load_b128(rw, (cov1 && cv_) ? woff1 + uw_ : 0xffffffffu, 0, 0);
+        char* bbase_ = &smem[buf][ABYTES + wu * 1024];
+        dma16(rw, bbase_, (cov0 && cv_) ? woff0 + uw_ : 0xffffffffu);
+        dma16(rw, bbase_ + 4096, (cov1 && cv_) ? woff1 + uw_ : 0xffffffffu);
         if (++cc == p.kchunks) {
             cc = 0; ++tap;
             if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
         }
     };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<u32x4*>(&smem[buf][lds_off(r0 + 64 * i, q)]) = p.relu_in ? relu16<T>(ra[i]) : ra[i];
-        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0, q)]) = rb0;
-        *reinterpret_cast<u32x4*>(&smem[buf][ABYTES + lds_off(r0 + 64, q)]) = rb1;
-    };
-#define CONV_GLOAD() gload()
-#define CONV_LSTORE(buf) lstore(buf)
 
     f32x16 acc[TM][2];
     {
@@ -322,20 +340,34 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
 
     const int arow = wm * (TM * 32) + (lane & 31), brow = wn * 64 + (lane & 31);
     if (k_begin < k_end) {
-        CONV_GLOAD();
-        CONV_LSTORE(0);
-        __syncthreads();
-        for (int ks = k_begin; ks < k_end; ++ks) {
-            const int buf = (ks - k_begin) & 1;
-            const bool more = ks + 1 < k_end;
-            if (more) CONV_GLOAD();
-            mma_swz<T, TM>(&smem[buf][0], &smem[buf][ABYTES], arow, brow, lane, acc);
-            if (more) CONV_LSTORE(buf ^ 1);
-            __syncthreads();
+        // 3-stage ring, two tiles in flight.  Waits are COUNTED (vmcnt(NA+2) keeps the youngest tile's
+        // DMAs outstanding) and the barrier is the raw s_barrier: __syncthreads() would make hipcc drain
+        // vmcnt(0) while an LDS-DMA is pending and collapse the pipeline to depth 1.
+        constexpr int kDmaPerTile = NA + 2;
+        constexpr int kWaitOne = (kDmaPerTile & 0xf) | (7 << 4) | (0xf << 8) | ((kDmaPerTile >> 4) << 14);
+        constexpr int kWaitAll = 0 | (7 << 4) | (0xf << 8);
+        const int nsteps = k_end - k_begin;
+        dma(0);
+        if (nsteps > 1) {
+            dma(1);
+            __builtin_amdgcn_s_waitcnt(kWaitOne);
+        } else {
+            __builtin_amdgcn_s_waitcnt(kWaitAll);
+        }
+        __builtin_amdgcn_s_barrier();
+        int st = 0, st2 = 2;                                   // stage of tile s, stage of tile s+2
+        for (int sidx = 0; sidx < nsteps; ++sidx) {
+            const bool issue = sidx + 2 < nsteps;
+            if (issue) dma(st2);                               // stage st2 was last read in step sidx-1
+            mma_swz<T, TM, RELU>(&smem[st][0], &smem[st][ABYTES], arow, brow, lane, acc);
+            if (issue) __builtin_amdgcn_s_waitcnt(kWaitOne);   // tile sidx+1 has landed (this wave's part)
+            else __builtin_amdgcn_s_waitcnt(kWaitAll);
+            __builtin_amdgcn_s_barrier();                      // ... and every other wave's part
+            st = st == NSTAGE - 1 ? 0 : st + 1;
+            st2 = st2 == NSTAGE - 1 ? 0 : st2 + 1;
         }
     }
-#undef CONV_GLOAD
-#undef CONV_LSTORE
+    __syncthreads();
 
     // ---- epilogue: accumulators -> LDS (per wave, 32 rows x 64 columns at a time) -> 8-column vectors.
     // Going through LDS keeps the register->LDS part trivially unrollable (a large branchy epilogue
@@ -718,13 +750,17 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == DVD_BF16) {
-        if (big) conv_igemm_kernel<bf16_t, 4><<<grid, NT, 0, st>>>(p);
-        else conv_igemm_kernel<bf16_t, 2><<<grid, NT, 0, st>>>(p);
-    } else if (d->dtype == DVD_F32) {
-        if (big) conv_igemm_kernel<float, 4><<<grid, NT, 0, st>>>(p);
-        else conv_igemm_kernel<float, 2><<<grid, NT, 0, st>>>(p);
-    } else return DVD_E_ARG;
+#define LAUNCH_CONV(TT)                                                                    \
+    do {                                                                                   \
+        if (big) { if (d->relu_in) conv_igemm_kernel<TT, 4, true><<<grid, NT, 0, st>>>(p);   \
+                   else conv_igemm_kernel<TT, 4, false><<<grid, NT, 0, st>>>(p); }           \
+        else     { if (d->relu_in) conv_igemm_kernel<TT, 2, true><<<grid, NT, 0, st>>>(p);   \
+                   else conv_igemm_kernel<TT, 2, false><<<grid, NT, 0, st>>>(p); }           \
+    } while (0)
+    if (d->dtype == DVD_BF16) LAUNCH_CONV(bf16_t);
+    else if (d->dtype == DVD_F32) LAUNCH_CONV(float);
+    else return DVD_E_ARG;
+#undef LAUNCH_CONV
     return launch_status();
 }
 
@@ -778,7 +814,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     ProfScope prof(1, 2.0 * (double)M * d->Cout * d->Cin_real * ntaps, stream, M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == DVD_BF16) {
+if (d->dtype == DVD_BF16) {
         if (ta == 4) conv_wgrad_kernel<bf16_t, 4, 2><<<grid, NT, 0, st>>>(p);
         else if (tb == 4) conv_wgrad_kernel<bf16_t, 2, 4><<<grid, NT, 0, st>>>(p);
         else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, NT, 0, st>>>(p);
