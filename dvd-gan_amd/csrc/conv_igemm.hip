@@ -796,9 +796,12 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     }
     const int ntaps = d->kt * d->kh * d->kw;
     long long msplit = d->msplit;
-    if (msplit < 1) {   // auto: enough workgroups to fill 256 CUs a few times over
+    if (msplit < 1) {   // auto: ~3 workgroups per CU, but every workgroup keeps >= 16k rows of reduction so
+                        // that its 32k-atomic epilogue stays small next to its MFMA work
         const long long base = (long long)p.tiles_co * p.tiles_ci * ntaps;
-        msplit = (1024 + base - 1) / base;
+        msplit = (768 + base - 1) / base;
+        const long long cap = M / 16384 > 0 ? M / 16384 : 1;
+        if (msplit > cap) msplit = cap;
     }
     long long rows = (M + msplit - 1) / msplit;
     {   // a workgroup's row slice is addressed with 32-bit byte offsets
