@@ -49,6 +49,17 @@ def parse():
     return ap.parse_args()
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel`, from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected with
+    rocprofv3 in separate runs and corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_hbm_traffic.json).
+    PMC collection cannot run inside the timed benchmark, so this is a recorded measurement of the same command."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(a):
     """One reference-equivalent step at B=1 on the host cores (oracle = checker, timed as baseline)."""
     from oracle import dvdgan_cpu as O
@@ -136,7 +147,7 @@ def main():
         dom = res["conv_igemm"]
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16> (forward + backward-data)" if a.dtype == "bf16" else "conv_igemm_kernel<f32>",
                 "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic("conv_igemm"),
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),
                 "gflop_per_launch": round(dom["gflop_per_launch"], 2), "kernel_ms_per_step": round(dom["ms"], 1),
                 "wgrad": {k: round(v, 2) if isinstance(v, float) else v for k, v in res["conv_wgrad"].items()},
