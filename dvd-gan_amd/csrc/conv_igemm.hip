@@ -405,6 +405,7 @@ struct WgK {
     long long s_co, s_ci, s_tap;
     size_t x_bytes, dy_bytes;
     int maxshift;
+    float* dbias;
 };
 
 // D[co][ci] = sum over rows m of dy[m][co] * x[pos(m)+tap][ci].  The reduction index (rows) is the
@@ -490,10 +491,20 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
             for (int i = 0; i < NPB; ++i)
                 rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + rrb + i * RPPB, cx * 2, cxv), 0, 0);
         };
+        // fused bias gradient: the centre-tap / first-ci-tile workgroups sum the dy chunks they stage
+        const bool do_bias = p.dbias != nullptr && dt == 0 && dy_ == 0 && dx == 0 && tci == 0;
+        float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         auto wg_lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < NPA; ++i)
+            for (int i = 0; i < NPA; ++i) {
                 *reinterpret_cast<u32x4*>(&smem[buf][(rra + i * RPPA) * RSA + cka * 16]) = ra[i];
+                if (do_bias) {
+                    bs[0] += __uint_as_float(ra[i].x << 16); bs[1] += __uint_as_float(ra[i].x & 0xffff0000u);
+                    bs[2] += __uint_as_float(ra[i].y << 16); bs[3] += __uint_as_float(ra[i].y & 0xffff0000u);
+                    bs[4] += __uint_as_float(ra[i].z << 16); bs[5] += __uint_as_float(ra[i].z & 0xffff0000u);
+                    bs[6] += __uint_as_float(ra[i].w << 16); bs[7] += __uint_as_float(ra[i].w & 0xffff0000u);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NPB; ++i)
                 *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + (rrb + i * RPPB) * RSB + ckb * 16]) =
@@ -517,19 +528,27 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
         auto mma = [&](int buf) __attribute__((always_inline)) {
             const char* At = &smem[buf][0];
             const char* Bt = &smem[buf][TA_BYTES];
+            // all fragment reads of the 32-row step are issued up front: the second half's transpose
+            // reads land while the first half's MFMAs run
+            bf16x8 fa0[TA], fb0[TB], fa1[TA], fb1[TB];
 #pragma unroll
-            for (int kb = 0; kb < 32; kb += 16) {
-                bf16x8 fa[TA], fb[TB];
+            for (int a = 0; a < TA; ++a) fa0[a] = frag(At, RSA, wm * (TA * 32) + a * 32, 0);
 #pragma unroll
-                for (int a = 0; a < TA; ++a) fa[a] = frag(At, RSA, wm * (TA * 32) + a * 32, kb);
+            for (int b = 0; b < TB; ++b) fb0[b] = frag(Bt, RSB, wn * (TB * 32) + b * 32, 0);
 #pragma unroll
-                for (int b = 0; b < TB; ++b) fb[b] = frag(Bt, RSB, wn * (TB * 32) + b * 32, kb);
+            for (int a = 0; a < TA; ++a) fa1[a] = frag(At, RSA, wm * (TA * 32) + a * 32, 16);
 #pragma unroll
-                for (int a = 0; a < TA; ++a)
+            for (int b = 0; b < TB; ++b) fb1[b] = frag(Bt, RSB, wn * (TB * 32) + b * 32, 16);
 #pragma unroll
-                    for (int b = 0; b < TB; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-            }
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[a], fb0[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[a], fb1[b], acc[a][b], 0, 0, 0);
         };
         if (m_begin < m_end) {
             WG_GLOAD(m_begin);
@@ -546,6 +565,21 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
         }
 #undef WG_GLOAD
 #undef WG_LSTORE
+        if (do_bias) {                                   // threads sharing a channel chunk: rra = 0..RPPA-1
+            float* red = reinterpret_cast<float*>(&smem[0][0]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
+            __syncthreads();
+            if (tid < CPRA) {
+                for (int k = 0; k < 8; ++k) {
+                    float a = 0.f;
+                    for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
+                    const int co = co0 + tid * 8 + k;
+                    if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+                }
+            }
+            __syncthreads();
+        }
     } else {
         // f32: LDS image [16 rows][WG_LD floats]; thread stages rows kr, kr+8, 16-byte chunk ch
         const int ch = tid & 31, kr = tid >> 5;
@@ -558,7 +592,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
             b0 = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + kr, cx * 4, cxv), 0, 0);
             b1 = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + kr + 8, cx * 4, cxv), 0, 0);
         };
+        const bool do_bias = p.dbias != nullptr && dt == 0 && dy_ == 0 && dx == 0 && tci == 0;
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
         auto lstore = [&](int buf) __attribute__((always_inline)) {
+            if (do_bias) {
+                bs[0] += __uint_as_float(a0.x) + __uint_as_float(a1.x); bs[1] += __uint_as_float(a0.y) + __uint_as_float(a1.y);
+                bs[2] += __uint_as_float(a0.z) + __uint_as_float(a1.z); bs[3] += __uint_as_float(a0.w) + __uint_as_float(a1.w);
+            }
             *reinterpret_cast<u32x4*>(&smem[buf][(kr * WG_LD + ch * 4) * 4]) = a0;
             *reinterpret_cast<u32x4*>(&smem[buf][((kr + 8) * WG_LD + ch * 4) * 4]) = a1;
             *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + (kr * WG_LD + ch * 4) * 4]) = p.relu_in ? relu16_f32(b0) : b0;
@@ -590,6 +630,21 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
                 if (more) lstore(buf ^ 1);
                 __syncthreads();
             }
+        }
+        if (do_bias) {                                   // threads sharing a channel chunk: kr = 0..7
+            float* red = reinterpret_cast<float*>(&smem[0][0]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[tid * 4 + k] = bs[k];
+            __syncthreads();
+            if (tid < 32) {
+                for (int k = 0; k < 4; ++k) {
+                    float a = 0.f;
+                    for (int r = 0; r < 8; ++r) a += red[(r * 32 + tid) * 4 + k];
+                    const int co = co0 + tid * 4 + k;
+                    if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+                }
+            }
+            __syncthreads();
         }
     }
 
@@ -785,7 +840,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
         else if (d->Cin_real >= 192) tb = 4;
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
-    p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap;
+    p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias;
     {
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
         const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;

@@ -68,14 +68,14 @@ class QKVConv(torch.autograd.Function):
         dx = K.conv_forward(dqkv, spec.pack.wd, (1, 1), spec.pack.cip) if ctx.needs_input_grad[0] else None
         outs = []
         need_w = ctx.needs_input_grad[1]
+        db = torch.zeros(spec.cout, dtype=torch.float32, device=x.device) if need_w else None
         for w, off, n in ((wq, 0, dq), (wk, dqp, dq), (wv, 2 * dqp, C_)):
             if need_w:
                 dw = torch.zeros_like(w)
-                K.conv_wgrad(x, dqkv, dw, (1, 1), n, C_, dy_col=off)
+                K.conv_wgrad(x, dqkv, dw, (1, 1), n, C_, dy_col=off, dbias=db[off:off + n])
                 outs.append(dw)
             else:
                 outs.append(None)
-        db = K.colsum(dqkv, spec.cout) if need_w else None
         dbq = db[:dq].clone() if need_w else None
         dbk = db[dqp:dqp + dq].clone() if need_w else None
         dbv = db[2 * dqp:].clone() if need_w else None

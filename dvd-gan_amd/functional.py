@@ -80,13 +80,15 @@ class Conv(Function):
                 dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None)
         if ctx.needs_input_grad[1]:
             G = torch.zeros_like(w)
-            K.conv_wgrad(x, dy, G, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in)
+            if ctx.needs_input_grad[2]:           # bias gradient rides along in the wgrad kernel
+                db = torch.zeros(spec.cout, dtype=torch.float32, device=dy.device)
+            K.conv_wgrad(x, dy, G, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=db)
             if spec.sn is not None:
                 u, v = spec.sn            # CURRENT u / v on purpose (reference quirk 7)
                 dw = K.sn_backward(G, w, u, v, ctx.sigma)
             else:
                 dw = G
-        if ctx.needs_input_grad[2]:
+        elif ctx.needs_input_grad[2]:
             db = K.colsum(dy, spec.cout)
         return dx, dw, db, (dy if ctx.has_res else None), None
 
@@ -227,9 +229,11 @@ class ConvGRULayer(Function):
         ctot = cin + hid
         hflat = h_all.view(T * B, S1, S2, hid)
         hrflat = hr_all.view(T * B, S1, S2, hid)
+        db3 = torch.zeros(3 * hid, dtype=torch.float32, device=dev)
         for g, w in enumerate((wu, wr, wo)):
             dw = torch.zeros_like(w)
-            K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot)
+            K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot,
+                         dbias=db3[g * hid:(g + 1) * hid])
             if h0 is not None:
                 raise RuntimeError("gradient through a supplied initial hidden state is not implemented")
             if T > 1:
@@ -241,7 +245,6 @@ class ConvGRULayer(Function):
                     K.conv_wgrad(hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
                                  frames=(T - 1) * B, x_row0=B, dy_row0=B)
             grads.append(dw)
-        db3 = K.colsum(dg, 3 * hid)
         return (dx, grads[0], db3[:hid].clone(), grads[1], db3[hid:2 * hid].clone(), grads[2], db3[2 * hid:].clone(),
                 None, None, None)
 

@@ -132,7 +132,7 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
 
 
 def conv_wgrad(x, dy, dw, ksize, cout, cin_real, *, up2=False, relu_in=False, msplit=0, dy_col=0,
-               dw_ci_off=0, dw_ci_tot=None, frames=None, x_row0=0, dy_row0=0):
+               dw_ci_off=0, dw_ci_tot=None, frames=None, x_row0=0, dy_row0=0, dbias=None):
     """dw[co][dw_ci_off + ci][*k] += sum_rows dy[row][dy_col + co] * x[shifted row][ci]   (fp32 atomics)
     dw: fp32 master-layout tensor [cout][dw_ci_tot][*k].  x / dy may be row-sliced views given by
     (tensor, first frame): `frames` frames starting at frame x_row0 of x and dy_row0 of dy."""
@@ -155,6 +155,7 @@ def conv_wgrad(x, dy, dw, ksize, cout, cin_real, *, up2=False, relu_in=False, ms
     d.x = x.data_ptr() + x_row0 * rows_in * x.shape[-1] * esz
     d.dy = dy.data_ptr() + (dy_row0 * T * H * W * dy.shape[-1] + dy_col) * esz
     d.dw = dw.data_ptr() + dw_ci_off * ntaps * 4
+    d.dbias = dbias.data_ptr() if dbias is not None else None      # fp32 [cout], accumulated
     L.check(L.lib().dvd_conv_wgrad(C.byref(d), L.stream()))
     return dw
 

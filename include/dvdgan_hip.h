@@ -94,6 +94,8 @@ typedef struct {
     const void* x;
     const void* dy;
     float* dw;
+    float* dbias;              /* optional: dbias[co] += sum_m dy[m][co] (bias gradient, fused: the centre-tap
+                                  workgroups already stream every dy row), co < Cout; NULL = skip          */
 } dvd_wgrad_desc;
 int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream);
 
