@@ -15,6 +15,7 @@
 // Backward walks t = T-1..0 with two backward-data convs per step; every weight gradient and the
 // x-path gradient are batched over all T by the caller afterwards (dg holds d(pre-activation)).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -194,12 +195,14 @@ int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int
         else return DVD_E_ARG;                                                 \
     } while (0)
 
-// Split-K factor that brings a conv with few output tiles up to ~one workgroup per CU.
+// Split-K factor that brings a conv with few output tiles up to ~two workgroups per CU (measured on the
+// full step: target 128 -> 948 ms, 256 -> 922, 384 -> 917, 512 -> 913).
 extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps) {
     const int bk = dtype == DVD_BF16 ? 32 : 16;
     const long long nk = (long long)ntaps * ((C + bk - 1) / bk);
     const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    long long ns = (256 + tiles - 1) / tiles;
+    static const long long target = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 512;
+    long long ns = (target + tiles - 1) / tiles;
     if (ns > 16) ns = 16;
     if (ns > nk) ns = nk;
     if (ns < 1) ns = 1;
