@@ -235,17 +235,19 @@ __device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, in
 // Workgroup = 2 x 2 waves, wave tile = (TM*32) x 64  =>  block tile BM = TM*64 rows x 128 columns.
 // TM = 4 (256 x 128) is the production shape: 16 MFMAs per wave between barriers and 6 instead of 8
 // fragment reads per 8 MFMAs; TM = 2 (128 x 128) serves problems with few rows.
-template <typename T, int TM, bool RELU>
-__global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
+template <typename T, int TM, int WN, bool RELU>   // waves: 2 (M) x WN (N); block tile (TM*64) x (WN*64)
+__global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     constexpr int E16 = ElemTraits<T>::kPer16B;
     constexpr int BK = 4 * E16;
-    constexpr int BMt = TM * 64;
-    constexpr int NA = BMt / 64;                       // activation rows staged per thread
-    constexpr int ABYTES = BMt * 64, BBYTES = BN * 64;
+    constexpr int BMt = TM * 64, BNt = WN * 64;
+    constexpr int NWAVE = 2 * WN;
+    constexpr int NA = BMt / 16 / NWAVE;               // 16-row DMA groups of the activation tile per wave
+    constexpr int NB = BNt / 16 / NWAVE;               // ... of the weight tile
+    constexpr int ABYTES = BMt * 64, BBYTES = BNt * 64;
     constexpr int NSTAGE = 3;                          // LDS ring: tile k is multiplied while k+1, k+2 are in flight
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE][ABYTES + BBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only);
     // give each XCD a contiguous run of tiles so the N-tiles of one M-tile share that XCD's L2.
     int bid = blockIdx.x;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
         bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
     }
     const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
-    const int m0 = mt * BMt, n0 = nt * BN;
+    const int m0 = mt * BMt, n0 = nt * BNt;
     const int z = blockIdx.z;
     const int per = (p.nk + p.nsplit - 1) / p.nsplit;
     const int k_begin = z * per;
@@ -274,13 +276,15 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
     bool av[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + (i * 4 + wu) * 16 + lrow;
+        const int m = m0 + (i * NWAVE + wu) * 16 + lrow;
         am[i] = m; av[i] = m < p.M;
         ax[i] = m & (p.W - 1); ay[i] = (m >> p.logW) & (p.H - 1);
         at[i] = p.kt > 1 ? (m >> (p.logW + p.logH)) % p.T : 0;
     }
-    const int co0 = n0 + wu * 16 + lrow, co1 = n0 + (4 + wu) * 16 + lrow;
-    const bool cov0 = co0 < p.Cout, cov1 = co1 < p.Cout;
+    int cob[NB];
+    bool cov[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { cob[j] = n0 + (j * NWAVE + wu) * 16 + lrow; cov[j] = cob[j] < p.Cout; }
     // Offsets are 32-bit, activations can exceed 4 GiB: the descriptor of the activation tensor starts
     // at the first input row this tile can touch (wave-uniform), offsets are relative to it.
     const unsigned ldb = (unsigned)p.ldi * (unsigned)esz;        // input row pitch in bytes
@@ -293,7 +297,9 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
     unsigned aoff[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) aoff[i] = (unsigned)(am[i] - base_row) * ldb + q * 16;
-    const unsigned woff0 = ((unsigned)co0 * p.C + q * E16) * (unsigned)esz, woff1 = ((unsigned)co1 * p.C + q * E16) * (unsigned)esz;
+    unsigned woff[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) woff[j] = ((unsigned)cob[j] * p.C + q * E16) * (unsigned)esz;
     // wave-uniform K-step state (tap decomposition kept incrementally)
     int tap = 0, cc = 0, it = 0, iy = 0, ix = 0;
     if (k_begin < k_end) {
@@ -317,12 +323,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
                 const int f_ = am[i] >> (p.logW + p.logH);
                 off_ = (unsigned)(((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1) - base_row) * ldb + cc * 64 + q * 16;
             }
-            dma16(rin, abase_ + i * 4096, ok_ ? off_ : 0xffffffffu);
+            dma16(rin, abase_ + i * (NWAVE * 1024), ok_ ? off_ : 0xffffffffu);
         }
         const unsigned uw_ = (unsigned)(tap * p.Cout) * (unsigned)p.C * (unsigned)esz + cc * 64;
         char* bbase_ = &smem[buf][ABYTES + wu * 1024];
-        dma16(rw, bbase_, (cov0 && cv_) ? woff0 + uw_ : 0xffffffffu);
-        dma16(rw, bbase_ + 4096, (cov1 && cv_) ? woff1 + uw_ : 0xffffffffu);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_) ? woff[j] + uw_ : 0xffffffffu);
         if (++cc == p.kchunks) {
             cc = 0; ++tap;
             if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvK p) {
         // 3-stage ring, two tiles in flight.  Waits are COUNTED (vmcnt(NA+2) keeps the youngest tile's
         // DMAs outstanding) and the barrier is the raw s_barrier: __syncthreads() would make hipcc drain
         // vmcnt(0) while an LDS-DMA is pending and collapse the pipeline to depth 1.
-        constexpr int kDmaPerTile = NA + 2;
+        constexpr int kDmaPerTile = NA + NB;
         constexpr int kWaitOne = (kDmaPerTile & 0xf) | (7 << 4) | (0xf << 8) | ((kDmaPerTile >> 4) << 14);
         constexpr int kWaitAll = 0 | (7 << 4) | (0xf << 8);
         const int nsteps = k_end - k_begin;
@@ -787,7 +793,12 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     p.nsplit = d->nsplit < 1 ? 1 : d->nsplit;
     if (p.nsplit > p.nk) p.nsplit = p.nk;
     if (p.nsplit != (d->nsplit < 1 ? 1 : d->nsplit)) return DVD_E_ARG;   // caller sized ws for d->nsplit slabs
-    p.tilesN = (d->Cout + BN - 1) / BN;
+    // 8-wave 256 x 256 tile when the output is wide enough (no more than 1/8 of the last N tile wasted)
+    // and there is at least one tile per CU; else 256 x 128 (>= 2 tiles per CU) or 128 x 128.
+    const long long t256 = cdiv(M, 256) * (long long)cdiv(d->Cout, 256) * p.nsplit;
+    const int rem256 = d->Cout % 256;
+    const bool wide = d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256 && !g;
+    p.tilesN = wide ? (d->Cout + 255) / 256 : (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};
     {   // extents of the two buffer descriptors (32-bit byte offsets): tensors must stay below 4 GiB
@@ -800,19 +811,22 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
-    const bool big = cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= 512;   // >= 2 workgroups per CU
+    const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= 512;   // >= 2 workgroups per CU
     dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_CONV(TT)                                                                    \
-    do {                                                                                   \
-        if (big) { if (d->relu_in) conv_igemm_kernel<TT, 4, true><<<grid, NT, 0, st>>>(p);   \
-                   else conv_igemm_kernel<TT, 4, false><<<grid, NT, 0, st>>>(p); }           \
-        else     { if (d->relu_in) conv_igemm_kernel<TT, 2, true><<<grid, NT, 0, st>>>(p);   \
-                   else conv_igemm_kernel<TT, 2, false><<<grid, NT, 0, st>>>(p); }           \
+#define LAUNCH_CONV(TT)                                                                       \
+    do {                                                                                      \
+        if (big) { if (d->relu_in) conv_igemm_kernel<TT, 4, 2, true><<<grid, NT, 0, st>>>(p);   \
+                   else conv_igemm_kernel<TT, 4, 2, false><<<grid, NT, 0, st>>>(p); }           \
+        else     { if (d->relu_in) conv_igemm_kernel<TT, 2, 2, true><<<grid, NT, 0, st>>>(p);   \
+                   else conv_igemm_kernel<TT, 2, 2, false><<<grid, NT, 0, st>>>(p); }           \
     } while (0)
-    if (d->dtype == DVD_BF16) LAUNCH_CONV(bf16_t);
+    if (wide) {
+        if (d->relu_in) conv_igemm_kernel<bf16_t, 4, 4, true><<<grid, 512, 0, st>>>(p);
+        else conv_igemm_kernel<bf16_t, 4, 4, false><<<grid, 512, 0, st>>>(p);
+    } else if (d->dtype == DVD_BF16) LAUNCH_CONV(bf16_t);
     else if (d->dtype == DVD_F32) LAUNCH_CONV(float);
     else return DVD_E_ARG;
 #undef LAUNCH_CONV

@@ -41,6 +41,8 @@ CASES = [
     (2, 8, 16, (6, 8, 8), (3, 3, 3), False, False),  # 3-D, T=6
     (1, 16, 8, (4, 4, 4), (1, 1, 1), False, False),
     (7, 136, 264, (4, 4), (3, 3), False, False),     # several K chunks, 3 N tiles, ragged M
+    (64, 16, 256, (32, 32), (3, 3), False, False),   # >= 256 tiles of 256x256: the 8-wave kernel
+    (66, 8, 512, (32, 32), (1, 1), False, True),     # 8-wave kernel, ReLU variant, ragged M, 2 N tiles
 ]
 
 

@@ -13,6 +13,8 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (64, 16, 1024, 512, 5, True),     # GRU#2 h-path
     (64, 8, 512, 512, 5, True),       # GRU#1 h-path (split-K)
     (3072, 32, 256, 384, 5, False),   # GRU#3 batched x-path
+    (3072, 16, 256, 1536, 5, False),  # GRU#2 batched x-path (wide N)
+    (3072, 16, 1536, 256, 5, False),  # its backward-data
     (3072, 16, 256, 256, 3, False),   # GResBlock 3x3
     (3072, 32, 128, 128, 3, False),
 ]
