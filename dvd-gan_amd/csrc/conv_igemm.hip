@@ -797,7 +797,7 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     // and there is at least one tile per CU; else 256 x 128 (>= 2 tiles per CU) or 128 x 128.
     const long long t256 = cdiv(M, 256) * (long long)cdiv(d->Cout, 256) * p.nsplit;
     const int rem256 = d->Cout % 256;
-    const bool wide = d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256 && !g;
+    const bool wide = d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
     p.tilesN = wide ? (d->Cout + 255) / 256 : (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};
