@@ -22,7 +22,10 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        if os.environ.get("DVD_SHARE_GPU0"):          # test aid: several ranks on one GPU (gloo backend)
+            local = 0
         torch.cuda.set_device(local)
+    backend = backend or os.environ.get("DVD_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
