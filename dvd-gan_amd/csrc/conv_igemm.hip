@@ -301,9 +301,13 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) woff[j] = ((unsigned)cob[j] * p.C + q * E16) * (unsigned)esz;
     // wave-uniform K-step state (tap decomposition kept incrementally)
+    // K order: channel chunk OUTER, taps INNER -- the 25 (9, 27) taps of one 64-byte channel chunk re-read
+    // the same few input rows back to back, so they hit L1/L2 instead of coming back after a whole sweep
+    // over C (which at 2 workgroups per CU is tens of MB per XCD, far beyond its 4 MiB L2).
+    const int ntaps = p.kt * p.kh * p.kw;
     int tap = 0, cc = 0, it = 0, iy = 0, ix = 0;
     if (k_begin < k_end) {
-        tap = k_begin / p.kchunks; cc = k_begin - tap * p.kchunks;
+        cc = k_begin / ntaps; tap = k_begin - cc * ntaps;
         it = tap / (p.kh * p.kw); const int rem = tap - it * p.kh * p.kw;
         iy = rem / p.kw; ix = rem - iy * p.kw;
     }
@@ -329,10 +333,9 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         char* bbase_ = &smem[buf][ABYTES + wu * 1024];
 #pragma unroll
         for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_) ? woff[j] + uw_ : 0xffffffffu);
-        if (++cc == p.kchunks) {
-            cc = 0; ++tap;
-            if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
-        }
+        ++tap;
+        if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
+        if (tap == ntaps) { tap = 0; it = 0; iy = 0; ix = 0; ++cc; }
     };
 
     f32x16 acc[TM][2];
