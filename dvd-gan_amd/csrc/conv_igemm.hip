@@ -879,11 +879,14 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     }
     const int ntaps = d->kt * d->kh * d->kw;
     long long msplit = d->msplit;
-    if (msplit < 1) {   // auto: ~3 workgroups per CU, but every workgroup keeps >= 16k rows of reduction so
-                        // that its 32k-atomic epilogue stays small next to its MFMA work
+    if (msplit < 1) {   // auto: ~6 workgroups per CU, but every workgroup keeps >= 8k rows of reduction so that
+                        // its 32k-atomic epilogue stays small next to its MFMA work (swept on the full step:
+                        // (768,16384) 327 ms of wgrad, (1536,8192) 320, (2048,4096) 337, (768,32768) 371)
+        static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 1536;
+        static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 8192;
         const long long base = (long long)p.tiles_co * p.tiles_ci * ntaps;
-        msplit = (768 + base - 1) / base;
-        const long long cap = M / 16384 > 0 ? M / 16384 : 1;
+        msplit = (tgt + base - 1) / base;
+        const long long cap = M / minrows > 0 ? M / minrows : 1;
         if (msplit > cap) msplit = cap;
     }
     long long rows = (M + msplit - 1) / msplit;
