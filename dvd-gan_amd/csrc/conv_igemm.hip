@@ -413,8 +413,9 @@ struct WgK {
     int tiles_co, tiles_ci, rows_per_split;
     long long s_co, s_ci, s_tap;
     size_t x_bytes, dy_bytes;
-    int maxshift, xcd_remap;
+    int maxshift, xcd_remap, skip_epi;
     float* dbias;
+    float* ws;                           // partial tiles [slice][x-block][BMc*BNc] when non-null
 };
 
 // D[co][ci] = sum over rows m of dy[m][co] * x[pos(m)+tap][ci].  The reduction index (rows) is the
@@ -682,16 +683,42 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
             const int ci = ci0 + wn * (TB * 32) + tb * 32 + (lane & 31);
             const int cob = co0 + wm * (TA * 32) + ta * 32 + (lane >> 5);
             float* dst = p.dw + ci * p.s_ci + tap * p.s_tap;
-            if (ci < p.Cin_real) {
+            if (p.ws) {
+                // partial tile of this row slice, tile-local [row][col] layout, coalesced plain stores
+                float* wt = p.ws + ((size_t)bz * gridDim.x + bx) * (size_t)(BMc * BNc) +
+                            (size_t)(wm * (TA * 32) + ta * 32) * BNc + wn * (TB * 32) + tb * 32;
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j)
+                    wt[(size_t)(2 * j + (lane >> 5)) * BNc + (lane & 31)] = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+            } else if (ci < p.Cin_real) {
 #pragma unroll 1
                 for (int j = 0; j < 16; ++j) {
                     const int co = cob + 2 * j;
                     const float v = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
-                    if (co < p.Cout && v != 0.f) atomicAdd(dst + co * p.s_co, v);
+                    if (co < p.Cout && v != 0.f && !p.skip_epi) atomicAdd(dst + co * p.s_co, v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+}
+
+// Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
+struct WgRedK { const float* ws; float* dw; int nslice, gx, gx_per_tap, tiles_ci, BMc, BNc, Cout, Cin_real; long long s_co, s_ci, s_tap; };
+__global__ void wgrad_reduce_kernel(WgRedK p) {
+    const int tile_elems = p.BMc * p.BNc;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)p.gx * tile_elems) return;
+    const int bx = (int)(i / tile_elems), e = (int)(i - (long long)bx * tile_elems);
+    const int r = e / p.BNc, c = e - r * p.BNc;
+    // decode bx exactly like the kernel: tap = bx / (tiles_co*tiles_ci), rem -> (tco, tci)
+    const int per_tap = p.gx_per_tap;
+    const int tap = bx / per_tap, rem = bx - tap * per_tap;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co = tco * p.BMc + r, ci = tci * p.BNc + c;
+    if (co >= p.Cout || ci >= p.Cin_real) return;
+    float a = 0.f;
+    for (int z = 0; z < p.nslice; ++z) a += p.ws[((size_t)z * p.gx + bx) * tile_elems + e];
+    p.dw[co * p.s_co + ci * p.s_ci + tap * p.s_tap] += a;
 }
 
 // ============================================================================ weight packing
@@ -846,42 +873,42 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     return launch_status();
 }
 
-extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
+// Validates a weight-gradient request and derives tile shape, grid and row split.
+static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit) {
     if (!d || !d->x || !d->dy || !d->dw) return DVD_E_ARG;
     const int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
     if (logH < 0 || logW < 0) return DVD_E_SHAPE;
     if ((d->C & 7) || (d->ldx & 7) || (d->Cy & 7) || (d->ldy & 7) || !(d->kt & d->kh & d->kw & 1)) return DVD_E_SHAPE;
     if (d->Cout > d->Cy || d->Cin_real > d->C) return DVD_E_ARG;
+    if (d->dtype != DVD_BF16 && d->dtype != DVD_F32) return DVD_E_ARG;
     const long long M = (long long)d->frames * d->T * d->H * d->W;
     if (M >= (1ll << 31) - 64) return DVD_E_SHAPE;
-    WgK p;
     p.x = (const char*)d->x; p.dy = (const char*)d->dy; p.dw = d->dw;
     p.M = (int)M; p.C = d->C; p.ldx = d->ldx; p.Cin_real = d->Cin_real; p.Cout = d->Cout; p.Cy = d->Cy; p.ldy = d->ldy;
     p.T = d->T; p.H = d->H; p.W = d->W; p.logH = logH; p.logW = logW;
     p.Hin = d->up2 ? d->H / 2 : d->H; p.Win = d->up2 ? d->W / 2 : d->W;
     p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.up2 = d->up2; p.relu_in = d->relu_in;
     // bf16: 256-wide tile along whichever channel axis is long enough (2x the MFMAs per barrier)
-    int ta = 2, tb = 2;
+    ta = 2; tb = 2;
     if (d->dtype == DVD_BF16) {
         if (d->Cout >= 192) ta = 4;
         else if (d->Cin_real >= 192) tb = 4;
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
-    p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias;
+    p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
     { static const int xr = getenv("DVD_WG_XCD") ? atoi(getenv("DVD_WG_XCD")) : 1; p.xcd_remap = xr; }
+    { static const int se = getenv("DVD_WG_SKIPEPI") ? atoi(getenv("DVD_WG_SKIPEPI")) : 0; p.skip_epi = se; }
     {
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
         const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;
-        const size_t xb = ((rows_in - 1) * (size_t)d->ldx + d->C) * esz;
-        const size_t yb = (((size_t)M - 1) * (size_t)d->ldy + d->Cy) * esz;
-        p.x_bytes = xb; p.dy_bytes = yb;
+        p.x_bytes = ((rows_in - 1) * (size_t)d->ldx + d->C) * esz;
+        p.dy_bytes = (((size_t)M - 1) * (size_t)d->ldy + d->Cy) * esz;
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
     }
     const int ntaps = d->kt * d->kh * d->kw;
-    long long msplit = d->msplit;
-    if (msplit < 1) {   // auto: ~6 workgroups per CU, but every workgroup keeps >= 8k rows of reduction so that
-                        // its 32k-atomic epilogue stays small next to its MFMA work (swept on the full step:
-                        // (768,16384) 327 ms of wgrad, (1536,8192) 320, (2048,4096) 337, (768,32768) 371)
+    msplit = d->msplit;
+    if (msplit < 1) {   // auto: ~6 workgroups per CU, every workgroup keeping >= 8k rows of reduction (swept on the
+                        // full step: (768,16384) 327 ms of wgrad, (1536,8192) 320, (2048,4096) 337, (768,32768) 371)
         static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 1536;
         static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 8192;
         const long long base = (long long)p.tiles_co * p.tiles_ci * ntaps;
@@ -899,16 +926,36 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     if (rows < 32) rows = 32;
     msplit = (M + rows - 1) / rows;
     p.rows_per_split = (int)rows;
-    dim3 grid(p.tiles_co * p.tiles_ci * ntaps, 1, (unsigned)msplit);
-    ProfScope prof(1, 2.0 * (double)M * d->Cout * d->Cin_real * ntaps, stream, M, d->C, d->Cout, ntaps, (int)msplit,
+    grid = dim3(p.tiles_co * p.tiles_ci * ntaps, 1, (unsigned)msplit);
+    return DVD_OK;
+}
+
+extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
+    WgK p; dim3 grid; int ta, tb; long long msplit;
+    if (wgrad_plan(d, p, grid, ta, tb, msplit) != DVD_OK || msplit <= 1) return 0;
+    return msplit * (long long)grid.x * (ta * 64) * (tb * 64);
+}
+
+extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
+    WgK p; dim3 grid; int ta, tb; long long msplit;
+    const int rc = wgrad_plan(d, p, grid, ta, tb, msplit);
+    if (rc != DVD_OK) return rc;
+    const int ntaps = d->kt * d->kh * d->kw;
+    if (d->ws && msplit > 1) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw
+    ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
-if (d->dtype == DVD_BF16) {
+    if (d->dtype == DVD_BF16) {
         if (ta == 4) conv_wgrad_kernel<bf16_t, 4, 2><<<grid, NT, 0, st>>>(p);
         else if (tb == 4) conv_wgrad_kernel<bf16_t, 2, 4><<<grid, NT, 0, st>>>(p);
         else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, NT, 0, st>>>(p);
-    } else if (d->dtype == DVD_F32) conv_wgrad_kernel<float, 2, 2><<<grid, NT, 0, st>>>(p);
-    else return DVD_E_ARG;
+    } else conv_wgrad_kernel<float, 2, 2><<<grid, NT, 0, st>>>(p);
+    if (p.ws) {
+        WgRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co * p.tiles_ci, p.tiles_ci, ta * 64, tb * 64, p.Cout,
+                 p.Cin_real, p.s_co, p.s_ci, p.s_tap};
+        const long long n = (long long)grid.x * r.BMc * r.BNc;
+        wgrad_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(r);
+    }
     return launch_status();
 }
 

@@ -156,6 +156,9 @@ def conv_wgrad(x, dy, dw, ksize, cout, cin_real, *, up2=False, relu_in=False, ms
     d.dy = dy.data_ptr() + (dy_row0 * T * H * W * dy.shape[-1] + dy_col) * esz
     d.dw = dw.data_ptr() + dw_ci_off * ntaps * 4
     d.dbias = dbias.data_ptr() if dbias is not None else None      # fp32 [cout], accumulated
+    nws = L.lib().dvd_conv_wgrad_ws_floats(C.byref(d))              # >0: deterministic two-phase reduction
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws > 0 else None
+    d.ws = ws.data_ptr() if ws is not None else None
     L.check(L.lib().dvd_conv_wgrad(C.byref(d), L.stream()))
     return dw
 

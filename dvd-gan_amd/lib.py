@@ -27,7 +27,7 @@ class WgradDesc(C.Structure):
                 ("ldy", C.c_int), ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("up2", C.c_int),
                 ("relu_in", C.c_int), ("msplit", C.c_int),
                 ("s_co", C.c_longlong), ("s_ci", C.c_longlong), ("s_tap", C.c_longlong),
-                ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
+                ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("ws", C.c_void_p)]
 
 
 def lib():
@@ -40,12 +40,13 @@ def lib():
                 "(dvd_gan_amd has no CPU / eager fallback)")
         _lib = C.CDLL(LIB_PATH)
         _lib.dvd_strerror.restype = C.c_char_p
+        _lib.dvd_conv_wgrad_ws_floats.restype = C.c_longlong
         if _lib.dvd_abi_version() != ABI_VERSION:
             raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
     return _lib
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def check(code):

@@ -96,8 +96,12 @@ typedef struct {
     float* dw;
     float* dbias;              /* optional: dbias[co] += sum_m dy[m][co] (bias gradient, fused: the centre-tap
                                   workgroups already stream every dy row), co < Cout; NULL = skip          */
+    float* ws;                 /* optional workspace of dvd_conv_wgrad_ws_floats(d) floats: row slices write
+                                  their partial tiles there with plain stores and a second kernel reduces
+                                  them into dw (deterministic, no atomics).  NULL = fp32 atomics on dw      */
 } dvd_wgrad_desc;
 int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream);
+long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d);   /* 0 = no workspace needed (single slice) */
 
 /* fp32 master weight [Cout][Cin][ntaps] (reference layout) -> the two operand packs:
  *   wf[tap][co][ci_pad]          forward            (Cin padded with zeros to Cip, multiple of 8)
