@@ -907,10 +907,11 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     }
     const int ntaps = d->kt * d->kh * d->kw;
     msplit = d->msplit;
-    if (msplit < 1) {   // auto: ~6 workgroups per CU, every workgroup keeping >= 8k rows of reduction (swept on the
-                        // full step: (768,16384) 327 ms of wgrad, (1536,8192) 320, (2048,4096) 337, (768,32768) 371)
-        static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 1536;
-        static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 8192;
+    if (msplit < 1) {   // auto: ~16 workgroups per CU, every workgroup keeping >= 4k rows of reduction.  Swept on the
+                        // full step with the workspace reduction (ms of wgrad per step): (1024,8192) 292,
+                        // (1536,8192) 267, (3072,4096) 247, (4096,4096) 243, (6144,4096) 242, (8192,2048) 252
+        static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 4096;
+        static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 4096;
         const long long base = (long long)p.tiles_co * p.tiles_ci * ntaps;
         msplit = (tgt + base - 1) / base;
         const long long cap = M / minrows > 0 ? M / minrows : 1;
