@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the measurements profiles/ is built from.
+#   bash tools/collect_evidence.sh <tag>      -> gpurun_out/ev_<tag>/{bench.json,stats.csv,shapes.txt,traffic.json}
+set -u
+tag=${1:-x}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/ev_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $root
+timeout 500 python bench.py > $out/bench.json 2> $out/bench.err
+tail -c 1500 $out/bench.json
+timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o st -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-prof > $out/prof.log 2>&1
+python tools/rocpd_summary.py /tmp/prof_$tag/st_results.db $out/stats.csv
+tail -1 $out/prof.log | cut -c1-160
+DVD_PROF_CSV=/tmp/shapes_$tag.csv timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python tools/prof_shapes.py /tmp/shapes_$tag.csv 60 > $out/shapes.txt
+timeout 900 rocprofv3 -i tools/pmc_traffic.txt --kernel-trace -d /tmp/pmc_$tag -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-prof > $out/pmc.log 2>&1
+python tools/traffic_summary.py /tmp/pmc_$tag $out/traffic.json "build $tag"
