@@ -81,6 +81,7 @@ struct ConvK {
     int up2, relu_in, act, out_f32;
     size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
     int maxshift;                        // largest |tap shift| in rows
+    int dbg;                             // timing experiments only (DVD_CONV_DBG), 0 in production
     GruEpi g;                            // optional fused ConvGRU gate epilogue (mode 0 = off)
 };
 
@@ -317,6 +318,9 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         // wave-uniform part of the offset: tap shift + channel chunk
         const unsigned udelta_ = (unsigned)(((dt_ * p.H + dy_) * p.W + dx_) * (int)ldb + cc * 64);
         char* abase_ = &smem[buf][wu * 1024];
+        const bool skipA_ = p.dbg == 2 || (p.dbg == 3 && tap != 0);
+        const bool oobA_ = p.dbg == 1 || (p.dbg == 4 && tap != 0);
+        if (!skipA_)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_, tt_ = at[i] + dt_;
@@ -327,12 +331,13 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
                 const int f_ = am[i] >> (p.logW + p.logH);
                 off_ = (unsigned)(((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1) - base_row) * ldb + cc * 64 + q * 16;
             }
-            dma16(rin, abase_ + i * (NWAVE * 1024), ok_ ? off_ : 0xffffffffu);
+            dma16(rin, abase_ + i * (NWAVE * 1024), (ok_ && !oobA_) ? off_ : 0xffffffffu);
         }
         const unsigned uw_ = (unsigned)(tap * p.Cout) * (unsigned)p.C * (unsigned)esz + cc * 64;
         char* bbase_ = &smem[buf][ABYTES + wu * 1024];
+        if (p.dbg != 2)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_) ? woff[j] + uw_ : 0xffffffffu);
+        for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_ && p.dbg != 1) ? woff[j] + uw_ : 0xffffffffu);
         ++tap;
         if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
         if (tap == ntaps) { tap = 0; it = 0; iy = 0; ix = 0; ++cc; }
@@ -365,10 +370,15 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         }
         __builtin_amdgcn_s_barrier();
         int st = 0, st2 = 2;                                   // stage of tile s, stage of tile s+2
+        const bool late = WN == 4 && wu >= NWAVE / 2 && !(p.dbg & 8);
         for (int sidx = 0; sidx < nsteps; ++sidx) {
             const bool issue = sidx + 2 < nsteps;
-            if (issue) dma(st2);                               // stage st2 was last read in step sidx-1
+            // 8-wave tiles put two waves on every SIMD: the second half issues its DMAs AFTER its MFMAs,
+            // so on each SIMD one wave's (slow to issue) LDS-DMAs sit beside its partner's MFMA burst
+            // instead of both waves stalling on DMA issue and then sharing the matrix pipe.
+            if (issue && !late) dma(st2);                      // stage st2 was last read in step sidx-1
             mma_swz<T, TM, RELU>(&smem[st][0], &smem[st][ABYTES], arow, brow, lane, acc);
+            if (issue && late) dma(st2);
             if (issue) __builtin_amdgcn_s_waitcnt(kWaitOne);   // tile sidx+1 has landed (this wave's part)
             else __builtin_amdgcn_s_waitcnt(kWaitAll);
             __builtin_amdgcn_s_barrier();                      // ... and every other wave's part
@@ -398,6 +408,283 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         for (int j = 0; j < 4; ++j) {
             const int row = rbase + j * 8 + erow;
             if (row < p.M && col < p.Cout)
+                conv_store8<T>(p, ep + (j * 8 + erow) * 64 + ecol, row, col, z);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ============================================================================ forward, halo-staged
+// Same GEMM as conv_igemm_kernel, but the activation operand is staged ONCE per channel chunk instead of
+// once per (chunk, tap).  The M tile is a 2-D patch of one frame (PH x 16 output pixels); its input
+// footprint -- the patch plus the filter halo, e.g. 20 x 20 rows for 5 x 5 taps on a 16 x 16 patch --
+// is brought into LDS by LDS-DMA (rows outside the frame use an out-of-range offset -> zeros), and the
+// 25 (9) taps then read their A fragments from that footprint at a per-tap row offset.  Only the weight
+// tile still moves per tap.  Why: with the tap-by-tap gather the DMA *issue* cost (not the traffic) was
+// the limiter -- timing experiments with the DMAs predicated off (DVD_CONV_DBG) put the MFMA/ds_read
+// loop alone at 1.3-1.7 PF/s and the same loop with only one A tile per chunk at +19..37 %.
+//   LDS: 2 halo buffers (chunk cc is multiplied while cc+1 lands) + 3-stage weight ring.
+//   kt = 3 (D_t's 3-D convs): the outer index runs over (chunk, dt) and the footprint comes from frame t+dt.
+// Footprint image in LDS: 64-byte rows (one channel chunk of one input pixel), row = hy * PITCH + hx with a
+// compile-time PITCH (20 = 16 + 2*2 columns; 12 when the nearest-x2 upsample is folded in), 16-byte slot
+// XOR-swizzled with ((hx >> 2) + SWA * hy) & 3.  Brute-forced over all taps and both ds_read_b128 lane groups:
+// conflict-free for 32 lanes = two 16-pixel patch lines (the row-index swizzle of the tap-by-tap kernel is
+// 2-way conflicted here because consecutive patch lines are PITCH, not 16, rows apart).
+template <bool UP2> struct HaloGeo {
+    static constexpr int PITCH = UP2 ? 12 : 20;
+    static constexpr int SWA = UP2 ? 2 : 0;
+    static __device__ __forceinline__ int sw(int hy, int hx) { return ((hx >> 2) + SWA * hy) & 3; }
+};
+
+template <typename T, int TM, int WN, bool RELU, bool UP2>   // waves: 2 (M) x WN (N); block tile (TM*64 pixels) x (WN*64)
+__global__ __launch_bounds__(128 * WN) void conv_halo_kernel(ConvK p) {
+    using G = HaloGeo<UP2>;
+    constexpr int PITCH = G::PITCH;
+    constexpr int E16 = ElemTraits<T>::kPer16B;
+    constexpr int BK = 4 * E16;
+    constexpr int BMt = TM * 64, BNt = WN * 64;
+    constexpr int NWAVE = 2 * WN;
+    constexpr int PH = BMt / 16;                              // patch: PH rows x 16 columns of one frame
+    constexpr int HG = UP2 ? ((PH / 2 + 3) * PITCH + 15) / 16 // 16-row DMA groups of the largest footprint
+                           : ((PH + 4) * PITCH + 15) / 16;    //   (5 x 5 taps)
+    constexpr int NH = (HG + NWAVE - 1) / NWAVE;              // footprint DMAs per wave
+    constexpr int NB = BNt / 16 / NWAVE;                      // weight-tile DMAs per wave
+    constexpr int HBYTES = HG * 1024, BBYTES = BNt * 64;
+    // weight ring depth: NSTAGE-1 tiles in flight.  4 where LDS allows (the 256 x 128 variant runs 2 workgroups per CU)
+    constexpr int NSTAGE = (TM == 4 && WN == 2) ? 3 : 4;
+    constexpr int EPI = NWAVE * 32 * 64 * 4;
+    constexpr int LDSB = 2 * HBYTES + 1024 + NSTAGE * BBYTES > EPI ? 2 * HBYTES + 1024 + NSTAGE * BBYTES : EPI;
+    __shared__ __attribute__((aligned(16))) char smem[LDSB];
+    char* const hbuf0 = &smem[0];
+    char* const dump = &smem[2 * HBYTES];                     // landing zone of the DMAs of non-existent groups
+    char* const bring = &smem[2 * HBYTES + 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
+    }
+    const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    const int n0 = nt * BNt;
+    // tile -> (frame, patch origin)
+    const int pw = p.W >> 4, ppf = pw * (p.H / PH);
+    const int ft = mt / ppf, pidx = mt - ft * ppf;
+    const int y0 = (pidx / pw) * PH, x0 = (pidx % pw) * 16;
+    const int z = blockIdx.z;
+    const int nouter = p.kchunks * p.kt;                      // outer index oc = cc * kt + it
+    const int per = (nouter + p.nsplit - 1) / p.nsplit;
+    const int oc_begin = z * per, oc_end = min(nouter, oc_begin + per);
+    const int ntap2 = p.kh * p.kw;
+    const unsigned esz = sizeof(T);
+    const int pad = p.kh >> 1, cpad = (pad + 1) >> 1;
+    // footprint extent in INPUT coordinates
+    const int HWa = UP2 ? ((15 + pad) >> 1) + cpad + 1 : 16 + 2 * pad;
+    const int HHa = UP2 ? ((PH - 1 + pad) >> 1) + cpad + 1 : PH + 2 * pad;
+    const int iy_lo = UP2 ? (y0 >> 1) - cpad : y0 - pad, ix_lo = UP2 ? (x0 >> 1) - cpad : x0 - pad;
+
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int lrow = lane >> 2;
+    const unsigned ldb = (unsigned)p.ldi * esz;
+    const int tt = p.kt > 1 ? ft % p.T : 0;                   // time index of this tile's frame
+    const int base_frame = max(0, ft - (p.kt >> 1));
+    const size_t fbytes = (size_t)p.Hin * p.Win * ldb;
+    const size_t base_b = (size_t)base_frame * fbytes;
+    const size_t left_b = p.in_bytes - base_b;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.in + base_b), 0, left_b > 0xfffffffeull ? 0xfffffffeu : (unsigned)left_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    unsigned hoff[NH];
+    int hq[NH];                                               // logical 16-byte slot this lane fetches, per group
+    bool hval[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int g = i * NWAVE + wu;
+        const int h = g * 16 + lrow;
+        const int hy = h / PITCH, hx = h - hy * PITCH;
+        const int yin = iy_lo + hy, xin = ix_lo + hx;
+        hq[i] = (lane & 3) ^ G::sw(hy, hx);
+        hval[i] = g < HG && hy < HHa && hx < HWa && (unsigned)yin < (unsigned)p.Hin && (unsigned)xin < (unsigned)p.Win;
+        hoff[i] = (unsigned)(yin * p.Win + xin) * ldb + hq[i] * 16;
+    }
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);             // weight tile: row-index swizzle as in conv_igemm_kernel
+    int cob[NB];
+    bool cov[NB];
+    unsigned woff[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        cob[j] = n0 + (j * NWAVE + wu) * 16 + lrow; cov[j] = cob[j] < p.Cout;
+        woff[j] = ((unsigned)cob[j] * p.C + q * E16) * esz;
+    }
+    // footprint of outer index oc -> halo buffer hb
+    auto dmaH = [&](int hb, int oc) __attribute__((always_inline)) {
+        const int cc_ = oc / p.kt, it_ = oc - cc_ * p.kt;
+        const int dt_ = it_ - (p.kt >> 1);
+        const bool ok_ = (unsigned)(tt + dt_) < (unsigned)p.T || p.kt == 1;
+        const unsigned ud_ = (unsigned)(ft + dt_ - base_frame) * (unsigned)fbytes + cc_ * 64;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int g = i * NWAVE + wu;
+            char* dst_ = g < HG ? hbuf0 + hb * HBYTES + g * 1024 : dump;
+            const bool cv_ = cc_ * BK + hq[i] * E16 < p.C;
+            dma16(rin, dst_, (hval[i] && ok_ && cv_) ? hoff[i] + ud_ : 0xffffffffu);
+        }
+    };
+    // weight tile of (chunk, tap): running iterator, two steps ahead of the multiply
+    int b_oc = oc_begin, b_tap = 0;
+    auto dmaB = [&](int stg) __attribute__((always_inline)) {
+        const int cc_ = b_oc / p.kt, it_ = b_oc - cc_ * p.kt;
+        const bool cv_ = cc_ * BK + q * E16 < p.C;
+        const unsigned uw_ = (unsigned)((it_ * ntap2 + b_tap) * p.Cout) * (unsigned)p.C * esz + cc_ * 64;
+        char* bbase_ = bring + stg * BBYTES + wu * 1024;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_) ? woff[j] + uw_ : 0xffffffffu);
+        if (++b_tap == ntap2) { b_tap = 0; ++b_oc; }
+    };
+
+    f32x16 acc[TM][2];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = zacc;
+    }
+
+    // this lane's A rows: pixel (py0 + 2 tm, px) of the patch for its TM 32-row sub-tiles.  Sub-tile tm sits
+    // 2 patch lines below sub-tile 0 -> a compile-time LDS offset (2 * PITCH rows; PITCH rows after the x2 fold)
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int px = l31 & 15, py0 = wm * (TM * 2) + (l31 >> 4);
+    constexpr int TMSTRIDE = (UP2 ? 1 : 2) * PITCH * 64;
+    const int brow = wn * 64 + l31;
+    const int nsteps = (oc_end - oc_begin) * ntap2;
+    if (nsteps > 0) {
+#define VMCNT(n) (((n) & 0xf) | (7 << 4) | (0xf << 8) | (((n) >> 4) << 14))
+        constexpr int FL = NSTAGE - 2;                         // weight tiles allowed to stay in flight past tile s+1
+        dmaH(0, oc_begin);
+#pragma unroll
+        for (int i = 0; i < NSTAGE - 1; ++i)
+            if (i < nsteps) dmaB(i);
+        if (nsteps > FL) __builtin_amdgcn_s_waitcnt(VMCNT(FL * NB));     // footprint + tile 0 landed
+        else __builtin_amdgcn_s_waitcnt(VMCNT(0));
+        __builtin_amdgcn_s_barrier();
+        const bool late = WN == 4 && wu >= NWAVE / 2;
+        int st = 0, st2 = NSTAGE - 1, hb = 0, m_oc = oc_begin, m_tap = 0, iy = 0, ix = 0;
+        for (int sidx = 0; sidx < nsteps; ++sidx) {
+            const bool issueB = sidx + NSTAGE - 1 < nsteps;
+            const bool issueH = m_tap == 0 && m_oc + 1 < oc_end;
+            if (!late) {
+                if (issueB) dmaB(st2);                         // stage st2 was last read in step sidx-1
+                if (issueH) dmaH(hb ^ 1, m_oc + 1);
+            }
+            {
+                // footprint row of this lane's sub-tile 0 for tap (iy, ix)
+                const int hy = UP2 ? ((py0 + iy - pad) >> 1) + cpad : py0 + iy;
+                const int hx = UP2 ? ((px + ix - pad) >> 1) + cpad : px + ix;
+                const int swz = G::sw(hy, hx);
+                const char* Ah = hbuf0 + hb * HBYTES + (hy * PITCH + hx) * 64;
+                const char* Bt = bring + st * BBYTES;
+                if constexpr (sizeof(T) == 2) {
+                    // Explicit software pipeline over the 2*TM (k-half, sub-tile) units: the fragment of unit
+                    // u+2 is requested right before the two MFMAs of unit u, pinned with sched_barrier.  (Left
+                    // alone hipcc recycles ONE A register set and waits lgkmcnt(0) before every MFMA pair;
+                    // all 12 reads up front instead stall on LDS issue: SQ_WAIT_INST_LDS 7x.)
+                    constexpr int NU = 2 * TM;
+                    bf16x8 b[2][2], a[NU];
+                    auto ldB = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn)
+                            b[kk][tn] = *reinterpret_cast<const bf16x8*>(Bt + lds_off(brow + tn * 32, kk * 2 + kh2));
+                    };
+                    auto ldA = [&](int u) __attribute__((always_inline)) {
+                        const int kk = u / TM, tm = u % TM, slot = kk * 2 + kh2;
+                        // after the x2 fold hy advances by 1 per sub-tile and SWA = 2: odd sub-tiles flip slot bit 1
+                        const int sl = (UP2 && (tm & 1)) ? (slot ^ 2) : slot;
+                        a[u] = *reinterpret_cast<const bf16x8*>(Ah + tm * TMSTRIDE + ((sl ^ swz) << 4));
+                    };
+                    ldB(0); ldA(0); ldA(1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        if (u + 2 < NU) {
+                            if ((u + 2) % TM == 0) ldB((u + 2) / TM);
+                            ldA(u + 2);
+                        }
+                        const int kk = u / TM, tm = u % TM;
+                        if constexpr (RELU) a[u] = __builtin_bit_cast(bf16x8, relu16_bf16(__builtin_bit_cast(u32x4, a[u])));
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[kk][tn], acc[tm][tn], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int k = kk * 2 + kh2;
+                        float b[2], a[TM];
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn)
+                            b[tn] = *reinterpret_cast<const float*>(Bt + lds_off(brow + tn * 32, k >> 2) + (k & 3) * 4);
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            const int sl = (UP2 && (tm & 1)) ? ((k >> 2) ^ 2) : (k >> 2);
+                            a[tm] = *reinterpret_cast<const float*>(Ah + tm * TMSTRIDE + ((sl ^ swz) << 4) + (k & 3) * 4);
+                            if constexpr (RELU) a[tm] = fmaxf(a[tm], 0.f);
+                        }
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < 2; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                    }
+                }
+            }
+            if (late) {
+                if (issueB) dmaB(st2);
+                if (issueH) dmaH(hb ^ 1, m_oc + 1);
+            }
+            // In-order completion: weight tile sidx+1 has landed once at most the FL younger tiles (plus, for the
+            // NSTAGE-1 steps after a footprint went out behind tile sidx+NSTAGE-1, that footprint) are outstanding.
+            {
+                const int younger = min(FL, nsteps - 2 - sidx);          // tiles issued beyond sidx+1
+                const bool hpend = m_tap < NSTAGE - 1 && m_oc + 1 < oc_end;
+                if (younger == FL) {
+                    if (hpend) __builtin_amdgcn_s_waitcnt(VMCNT(FL * NB + NH));
+                    else __builtin_amdgcn_s_waitcnt(VMCNT(FL * NB));
+                } else if (FL == 2 && younger == 1) {
+                    __builtin_amdgcn_s_waitcnt(VMCNT(NB));
+                } else {
+                    __builtin_amdgcn_s_waitcnt(VMCNT(0));
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            st = st == NSTAGE - 1 ? 0 : st + 1;
+            st2 = st2 == NSTAGE - 1 ? 0 : st2 + 1;
+            ++m_tap;
+            if (++ix == p.kw) { ix = 0; ++iy; }
+            if (m_tap == ntap2) { m_tap = 0; iy = 0; ix = 0; ++m_oc; hb ^= 1; }
+        }
+#undef VMCNT
+    }
+    __syncthreads();
+
+    float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 64);
+    const int ecol = (lane & 7) * 8, erow = lane >> 3;
+    const int frame_row0 = ft * (p.H * p.W);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int col = n0 + wn * 64 + ecol;
+        for (int j = 0; j < 4; ++j) {
+            const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;      // pixel of the patch, row-major 16 wide
+            const int row = frame_row0 + (y0 + (pi >> 4)) * p.W + x0 + (pi & 15);
+            if (col < p.Cout)
                 conv_store8<T>(p, ep + (j * 8 + erow) * 64 + ecol, row, col, z);
         }
         __builtin_amdgcn_wave_barrier();
@@ -837,7 +1124,13 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     // and there is at least one tile per CU; else 256 x 128 (>= 2 tiles per CU) or 128 x 128.
     const long long t256 = cdiv(M, 256) * (long long)cdiv(d->Cout, 256) * p.nsplit;
     const int rem256 = d->Cout % 256;
-    const bool wide = d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
+    // halo-staged kernel: square 3x3 / 5x5 (x3) filters on frames at least one 16 x 16 patch large.  It runs as
+    // 4-wave workgroups only: with the activation DMAs gone, two 256 x 128 workgroups per CU beat one 8-wave
+    // 256 x 256 workgroup (1.13-1.34 vs 0.86-1.12 PF/s on the S = 16 / 32 shapes of config C2).
+    static const int use_halo = getenv("DVD_CONV_HALO") ? atoi(getenv("DVD_CONV_HALO")) : 1;
+    const bool halo = use_halo && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->W >= 16 && d->H >= 16 &&
+                      p.nsplit <= p.kchunks * d->kt;
+    const bool wide = !halo && d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
     p.tilesN = wide ? (d->Cout + 255) / 256 : (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};
@@ -849,6 +1142,7 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         if (wb >= 0xffffffffull) return DVD_E_SHAPE;
         p.in_bytes = inb; p.w_bytes = (unsigned)wb;
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
+        { static const int dbg = getenv("DVD_CONV_DBG") ? atoi(getenv("DVD_CONV_DBG")) : 0; p.dbg = dbg; }
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= 512;   // >= 2 workgroups per CU
@@ -856,6 +1150,19 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
     hipStream_t st = (hipStream_t)stream;
+    if (halo) {
+#define LAUNCH_HALO2(TT, TM_, WN_, RL_)                                                             \
+        do { if (d->up2) conv_halo_kernel<TT, TM_, WN_, RL_, true><<<grid, 128 * WN_, 0, st>>>(p);      \
+             else conv_halo_kernel<TT, TM_, WN_, RL_, false><<<grid, 128 * WN_, 0, st>>>(p); } while (0)
+#define LAUNCH_HALO(TT, TM_, WN_)                                                                   \
+        do { if (d->relu_in) LAUNCH_HALO2(TT, TM_, WN_, true); else LAUNCH_HALO2(TT, TM_, WN_, false); } while (0)
+        if (d->dtype == DVD_BF16) { if (big) LAUNCH_HALO(bf16_t, 4, 2); else LAUNCH_HALO(bf16_t, 2, 2); }
+        else if (d->dtype == DVD_F32) { if (big) LAUNCH_HALO(float, 4, 2); else LAUNCH_HALO(float, 2, 2); }
+        else return DVD_E_ARG;
+#undef LAUNCH_HALO
+#undef LAUNCH_HALO2
+        return launch_status();
+    }
 #define LAUNCH_CONV(TT)                                                                       \
     do {                                                                                      \
         if (big) { if (d->relu_in) conv_igemm_kernel<TT, 4, 2, true><<<grid, NT, 0, st>>>(p);   \

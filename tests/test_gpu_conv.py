@@ -43,6 +43,13 @@ CASES = [
     (7, 136, 264, (4, 4), (3, 3), False, False),     # several K chunks, 3 N tiles, ragged M
     (64, 16, 256, (32, 32), (3, 3), False, False),   # >= 256 tiles of 256x256: the 8-wave kernel
     (66, 8, 512, (32, 32), (1, 1), False, True),     # 8-wave kernel, ReLU variant, ragged M, 2 N tiles
+    # halo-staged kernel (frames >= one 16-wide patch, 3x3 / 5x5 filters)
+    (3, 72, 40, (16, 16), (5, 5), False, False),     # 128-pixel patches, three K chunks (split-K over chunks)
+    (2, 24, 40, (16, 16), (3, 3), True, True),       # nearest x2 folded into the footprint, ReLU on fragments
+    (2, 16, 24, (16, 64), (3, 3), False, False),     # H != W
+    (1, 8, 16, (4, 16, 16), (3, 3, 3), False, False),  # 3-D: footprint from frame t+dt
+    (32, 16, 40, (64, 64), (5, 5), False, True),     # 512 tiles of 256 x 128: the 16 x 16 patch variant
+    (16, 40, 264, (64, 64), (5, 5), False, False),   # 8-wave 256 x 256 variant, 5x5, ragged N
 ]
 
 

@@ -1,5 +1,5 @@
 """Times single conv_igemm / conv_wgrad launches on representative C2 shapes (HIP events).
-usage: python tools/conv_microbench.py [fwd|wgrad|all] [iters]"""
+usage: python tools/conv_microbench.py [fwd|wgrad|all] [iters] [shape indices, e.g. 3,4]"""
 import os
 import sys
 
@@ -37,7 +37,8 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     dev, dt = "cuda", torch.bfloat16
-    for F_, S, Cin, Cout, k, slabs in SHAPES:
+    sel = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(SHAPES))
+    for F_, S, Cin, Cout, k, slabs in [SHAPES[i] for i in sel]:
         x = torch.randn(F_, S, S, Cin, device=dev).to(dt)
         pk = K.PackedConv(dt, Cout, Cin, (k, k), dev).fill(torch.randn(Cout, Cin, k, k, device=dev) * 0.05)
         M = F_ * S * S
