@@ -858,15 +858,19 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[a], fb1[b], acc[a][b], 0, 0, 0);
         };
         if (m_begin < m_end) {
+            // Step k: the tile k+1 (loaded during step k-1) goes to LDS FIRST, then the loads of tile k+2 are
+            // issued, then the MFMAs of tile k.  The LDS writes thus have a whole MFMA phase to land before the
+            // barrier (writes last -> write + barrier + first-read latency exposed every step: ceiling ~1 PF/s
+            // even with the memory traffic switched off).  Loads past the row slice are out-of-range -> zeros.
             WG_GLOAD(m_begin);
             WG_LSTORE(0);
+            WG_GLOAD(m_begin + BKW);
             __syncthreads();
             int buf = 0;
             for (int mk = m_begin; mk < m_end; mk += BKW, buf ^= 1) {
-                const bool more = mk + BKW < m_end;
-                if (more) WG_GLOAD(mk + BKW);
+                WG_LSTORE(buf ^ 1);
+                WG_GLOAD(mk + 2 * BKW);
                 mma(buf);
-                if (more) WG_LSTORE(buf ^ 1);
                 __syncthreads();
             }
         }

@@ -9,7 +9,7 @@ namespace {
 // ----------------------------------------------------------------------------- BN statistics
 // sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2          (fp64 atomics, caller zeroes)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, long long rows, int C, int ld, double* sums) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long long rows, int C, int ld, double* sums) {
     __shared__ double red[256][17];
     const int cg = (C + 7) / 8, nj = 256 / cg;
     const int g = threadIdx.x % cg, j = threadIdx.x / cg;
@@ -17,11 +17,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, long long row
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.0;
     if (j < nj) {
-        for (long long r = (long long)blockIdx.x * nj + j; r < rows; r += (long long)gridDim.x * nj) {
-            float v[8];
-            load8<T>(x + (size_t)r * ld + g * 8, v);
+        constexpr int U = 4;                                  // independent 16-byte loads in flight per thread
+        const long long stride = (long long)gridDim.x * nj;
+        for (long long r = (long long)blockIdx.x * nj + j; r < rows; r += stride * U) {
+            float v[U][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s[i] += v[i]; q[i] += (double)v[i] * v[i]; }
+            for (int u = 0; u < U; ++u) {
+                const long long ru = r + u * stride;
+                if (ru < rows) load8<T>(x + (size_t)ru * ld + g * 8, v[u]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[u][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s[i] += v[u][i]; q[i] += (double)v[u][i] * v[u][i]; }
         }
     }
 #pragma unroll
@@ -63,28 +75,47 @@ __global__ void bn_finalize_kernel(const double* sums, double n, int C, float ep
 
 // ----------------------------------------------------------------------------- CBN apply
 // y = act(gb[s][c] * (x - mean[c]) * rstd[c] + gb[s][C + c]),  s = samp[row / P]
+// grid (frames, pixel chunks): every pixel of a frame shares one condition row, so the 4 x 8 per-channel
+// constants live in registers and the loop is load -> 3 flops -> store with U vectors in flight.  (The first form
+// looked all 32 constants up per 16-byte vector: 0.6-1.2 TB/s.)
 template <typename T>
-__global__ void cbn_apply_kernel(const T* x, T* y, long long rows, int P, int C, int ld, const float* mean,
-                                 const float* rstd, const float* gb, const int* samp, int relu) {
-    const int cg = ld / 8;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cg) return;
-    const long long r = i / cg;
-    const int g = (int)(i - r * cg);
-    const float* gbs = gb + (size_t)samp[r / P] * 2 * C;
-    float v[8], o[8];
-    load8<T>(x + (size_t)r * ld + g * 8, v);
+__global__ __launch_bounds__(256) void cbn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int P, int C, int ld,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gb, const int* __restrict__ samp,
+                                                        int relu, int chunk) {
+    const int cg = ld / 8, nj = 256 / cg;
+    const int g = threadIdx.x % cg, j = threadIdx.x / cg;
+    if (j >= nj) return;
+    const int frame = blockIdx.x;
+    const float* gbs = gb + (size_t)samp[frame] * 2 * C;
+    float gam[8], bet[8], mu[8], rs[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = g * 8 + k;
-        float t = 0.f;
-        if (c < C) {
-            t = gbs[c] * ((v[k] - mean[c]) * rstd[c]) + gbs[C + c];
-            if (relu) t = fmaxf(t, 0.f);
-        }
-        o[k] = t;
+        const bool ok = c < C;
+        gam[k] = ok ? gbs[c] : 0.f; bet[k] = ok ? gbs[C + c] : 0.f;
+        mu[k] = ok ? mean[c] : 0.f; rs[k] = ok ? rstd[c] : 0.f;
     }
-    store8<T>(y + (size_t)r * ld + g * 8, o);
+    const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+    const size_t base = (size_t)frame * P * ld + g * 8;
+    constexpr int U = 4;
+    for (int p = p0 + j; p < p1; p += nj * U) {
+        float v[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (p + u * nj < p1) load8<T>(x + base + (size_t)(p + u * nj) * ld, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u * nj >= p1) break;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t = gam[k] * ((v[u][k] - mu[k]) * rs[k]) + bet[k];
+                o[k] = relu ? fmaxf(t, 0.f) : t;
+            }
+            store8<T>(y + base + (size_t)(p + u * nj) * ld, o);
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------- CBN backward
@@ -96,8 +127,8 @@ __global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const T* g, const T
     __shared__ float red[256][17];
     const int cg = (C + 7) / 8, nj = 256 / cg;
     const int gi = threadIdx.x % cg, j = threadIdx.x / cg;
-    const int frame = blockIdx.y;
-    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    const int frame = blockIdx.x;
+    const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
     float dg[8], db[8], mu[8], rs[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -151,34 +182,52 @@ __global__ void cbn_bwd_sums_kernel(const float* gb, const float* dgb, int B, in
     s12[C + c] = (float)b;
 }
 
-// dx = rstd * (gm * gamma_s - s1/N - xhat * s2/N)
+// dx = rstd * (gm * gamma_s - s1/N - xhat * s2/N);  grid (pixel chunks, frames), constants in registers
 template <typename T>
-__global__ void cbn_bwd_apply_kernel(const T* g, const T* a, const T* x, T* dx, long long rows, int P, int C, int ld,
-                                     const float* mean, const float* rstd, const float* gb, const int* samp,
-                                     const float* s12, float inv_n, int relu) {
-    const int cg = ld / 8;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cg) return;
-    const long long r = i / cg;
-    const int gi = (int)(i - r * cg);
-    const float* gbs = gb + (size_t)samp[r / P] * 2 * C;
-    const size_t off = (size_t)r * ld + gi * 8;
-    float gv[8], av[8], xv[8], o[8];
-    load8<T>(g + off, gv);
-    load8<T>(x + off, xv);
-    if (relu) load8<T>(a + off, av);
+__global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ a,
+                                                            const T* __restrict__ x, T* __restrict__ dx, int P, int C, int ld,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gb, const int* __restrict__ samp,
+                                                            const float* __restrict__ s12, float inv_n, int relu, int chunk) {
+    const int cg = ld / 8, nj = 256 / cg;
+    const int gi = threadIdx.x % cg, j = threadIdx.x / cg;
+    if (j >= nj) return;
+    const int frame = blockIdx.x;
+    const float* gbs = gb + (size_t)samp[frame] * 2 * C;
+    float gam[8], mu[8], rs[8], s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = gi * 8 + k;
-        float t = 0.f;
-        if (c < C) {
-            const float gm = (!relu || av[k] > 0.f) ? gv[k] : 0.f;
-            const float xh = (xv[k] - mean[c]) * rstd[c];
-            t = rstd[c] * (gm * gbs[c] - s12[c] * inv_n - xh * s12[C + c] * inv_n);
-        }
-        o[k] = t;
+        const bool ok = c < C;
+        gam[k] = ok ? gbs[c] : 0.f; mu[k] = ok ? mean[c] : 0.f; rs[k] = ok ? rstd[c] : 0.f;
+        s1[k] = ok ? s12[c] * inv_n : 0.f; s2[k] = ok ? s12[C + c] * inv_n : 0.f;
     }
-    store8<T>(dx + off, o);
+    const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+    const size_t base = (size_t)frame * P * ld + gi * 8;
+    constexpr int U = 2;
+    for (int p = p0 + j; p < p1; p += nj * U) {
+        float gv[U][8], xv[U][8], av[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (p + u * nj < p1) {
+                const size_t off = base + (size_t)(p + u * nj) * ld;
+                load8<T>(g + off, gv[u]);
+                load8<T>(x + off, xv[u]);
+                if (relu) load8<T>(a + off, av[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u * nj >= p1) break;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gm = (!relu || av[u][k] > 0.f) ? gv[u][k] : 0.f;
+                const float xh = (xv[u][k] - mu[k]) * rs[k];
+                o[k] = rs[k] * (gm * gam[k] - s1[k] - xh * s2[k]);
+            }
+            store8<T>(dx + base + (size_t)(p + u * nj) * ld, o);
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------- pooling / resampling
@@ -353,8 +402,8 @@ extern "C" int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int
     if (!x || !sums || rows <= 0 || C <= 0) return DVD_E_ARG;
     if ((ld & 7) || C > ld || (C + 7) / 8 > 256) return DVD_E_SHAPE;
     const int nj = 256 / ((C + 7) / 8);
-    unsigned grid = cdiv(rows, (long long)nj * 8);
-    if (grid > 2048) grid = 2048;
+    unsigned grid = cdiv(rows, (long long)nj * 16);
+    if (grid > 512) grid = 512;             // every block ends with 2C fp64 atomics on the same addresses (U = 8 / 1024 blocks measured slower)
     BY_DTYPE(dtype, bn_stats_kernel<T><<<grid, 256, 0, S_>>>((const T*)x, rows, C, ld, sums));
     return launch_status();
 }
@@ -372,9 +421,10 @@ extern "C" int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames
                              void* stream) {
     if (!x || !y || !mean || !rstd || !gb || !samp || frames <= 0 || P <= 0) return DVD_E_ARG;
     if ((ld & 7) || C > ld) return DVD_E_SHAPE;
-    const long long rows = frames * P, n = rows * (ld / 8);
-    BY_DTYPE(dtype, cbn_apply_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, rows, P, C, ld, mean, rstd,
-                                                                      gb, samp, relu));
+    if (ld / 8 > 256) return DVD_E_SHAPE;
+    const int nj = 256 / (ld / 8), chunk = nj * 16;          // 16 pixels per thread
+    dim3 grid((unsigned)frames, cdiv(P, chunk));
+    BY_DTYPE(dtype, cbn_apply_kernel<T><<<grid, 256, 0, S_>>>((const T*)x, (T*)y, P, C, ld, mean, rstd, gb, samp, relu, chunk));
     return launch_status();
 }
 
@@ -383,17 +433,18 @@ extern "C" int dvd_cbn_backward(int dtype, const void* g, const void* a, const v
                                 const int* samp, int B, float* dgb, float* s12, int relu, void* stream) {
     if (!g || !x || !dx || !mean || !rstd || !gb || !samp || !dgb || !s12 || (relu && !a)) return DVD_E_ARG;
     if (frames <= 0 || P <= 0 || B <= 0) return DVD_E_ARG;
-    if ((ld & 7) || C > ld || (C + 7) / 8 > 256) return DVD_E_SHAPE;
+    if ((ld & 7) || C > ld || ld / 8 > 256) return DVD_E_SHAPE;
     const int chunk = 2048;
-    dim3 grid(cdiv(P, chunk), (unsigned)frames);
+    dim3 grid((unsigned)frames, cdiv(P, chunk));
     BY_DTYPE(dtype, cbn_bwd_reduce_kernel<T><<<grid, 256, 0, S_>>>((const T*)g, (const T*)a, (const T*)x, P, C, ld,
                                                                    mean, rstd, samp, dgb, relu, chunk));
     cbn_bwd_sums_kernel<<<cdiv(C, 128), 128, 0, S_>>>(gb, dgb, B, C, s12);
-    const long long rows = frames * P, n = rows * (ld / 8);
+    const long long rows = frames * P;
     const float inv_n = (float)(1.0 / (double)rows);
-    BY_DTYPE(dtype, cbn_bwd_apply_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)g, (const T*)a, (const T*)x,
-                                                                          (T*)dx, rows, P, C, ld, mean, rstd, gb,
-                                                                          samp, s12, inv_n, relu));
+    const int nj = 256 / (ld / 8), chunk2 = nj * 16;
+    dim3 grid2((unsigned)frames, cdiv(P, chunk2));
+    BY_DTYPE(dtype, cbn_bwd_apply_kernel<T><<<grid2, 256, 0, S_>>>((const T*)g, (const T*)a, (const T*)x, (T*)dx, P, C,
+                                                                   ld, mean, rstd, gb, samp, s12, inv_n, relu, chunk2));
     return launch_status();
 }
 
