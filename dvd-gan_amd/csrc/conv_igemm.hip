@@ -858,19 +858,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[a], fb1[b], acc[a][b], 0, 0, 0);
         };
         if (m_begin < m_end) {
-            // Step k: the tile k+1 (loaded during step k-1) goes to LDS FIRST, then the loads of tile k+2 are
-            // issued, then the MFMAs of tile k.  The LDS writes thus have a whole MFMA phase to land before the
-            // barrier (writes last -> write + barrier + first-read latency exposed every step: ceiling ~1 PF/s
-            // even with the memory traffic switched off).  Loads past the row slice are out-of-range -> zeros.
             WG_GLOAD(m_begin);
             WG_LSTORE(0);
-            WG_GLOAD(m_begin + BKW);
             __syncthreads();
             int buf = 0;
             for (int mk = m_begin; mk < m_end; mk += BKW, buf ^= 1) {
-                WG_LSTORE(buf ^ 1);
-                WG_GLOAD(mk + 2 * BKW);
+                const bool more = mk + BKW < m_end;
+                if (more) WG_GLOAD(mk + BKW);
                 mma(buf);
+                if (more) WG_LSTORE(buf ^ 1);
                 __syncthreads();
             }
         }
@@ -991,6 +987,247 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
             }
             __builtin_amdgcn_wave_barrier();
         }
+}
+
+// ============================================================================ backward-weight, one filter ROW per workgroup
+// Same contraction as conv_wgrad_kernel, regrouped so the staged operands are reused across taps: a workgroup owns
+// (filter row iy, 64*WM out-channels, 64 in-channels) and ALL KW taps of that row.  Per 32-pixel step it stages
+// the dy rows once and the input FOOTPRINT of the step -- the 32 pixels plus KW-1 halo columns (two 16-pixel lines
+// when W = 16) -- once; the B fragment of tap ix is the same footprint read ix rows further on.  Bytes staged per
+// MFMA drop from 384 (256 x 128 tile, one tap) to ~130, and dy / x are fetched from L2 KH instead of KH*KW times.
+//   waves: WM (64 out-channels each) x 2 (32 in-channels each); wave tile 64 x (KW taps x 32) = 2 x KW accumulators
+//   LDS:   dy [32 rows][64*WM ch] (+64 B pad, transposing reads as in conv_wgrad_kernel);
+//          x  [2 halves of 32 ch][40 rows][64 B]: the 4 consecutive rows a ds_read_b64_tr_b16 pass touches are
+//             256 contiguous bytes (conflict-free without a swizzle) and a tap is a +64-byte immediate offset.
+template <int WM, int KW, bool RELU>
+__global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
+    constexpr int NTt = WM * 128, BMc = WM * 64;
+    constexpr int RSA = BMc * 2 + 64;
+    constexpr int TA_BYTES = 32 * RSA;
+    constexpr int XROWS = 40, XHALF = XROWS * 64, TB_BYTES = 2 * XHALF;
+    constexpr int STAGE = TA_BYTES + TB_BYTES;
+    constexpr int EPIB = WM * 2 * 32 * 32 * 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE > EPIB ? 2 * STAGE : EPIB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, total = gx * gridDim.z, lin = bx + gx * bz;
+        const int xcd = lin & 7, qd = total >> 3, rr = total & 7;
+        const int lp = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (lin >> 3);
+        bz = lp / gx; bx = lp - bz * gx;
+    }
+    const int tiles = p.tiles_co * p.tiles_ci;
+    const int iy = bx / tiles;
+    const int rem = bx - iy * tiles;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co0 = tco * BMc, ci0 = tci * 64;
+    constexpr int pad = KW >> 1;
+    const int dyl = iy - pad;
+    const int m_begin = bz * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    f32x16 acc[2][KW];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < KW; ++t) acc[a][t] = zacc;
+    }
+    const int xbase_row = max(0, m_begin - p.maxshift);
+    const size_t xbase_b = (size_t)xbase_row * p.ldx * 2, ybase_b = (size_t)m_begin * p.ldy * 2;
+    const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + xbase_b), 0, xleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)xleft, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ybase_b), 0, yleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)yleft, 0x00020000);
+    // step geometry: 32 pixels = one 32-pixel segment of a line (W >= 32) or two 16-pixel lines (W = 16)
+    const int segw = min(p.W, 32), fpr = segw + KW - 1, frows = (32 / segw) * fpr;
+    // dy loader: NPA 16-byte chunks per thread
+    constexpr int CPRA = BMc / 8, RPPA = NTt / CPRA, NPA = 32 / RPPA;
+    const int rra = tid / CPRA, cka = tid % CPRA;
+    const int cy = co0 + cka * 8;
+    const bool cyv = cy < p.Cy;
+    // x footprint loader: XROWS * 8 chunks over NTt threads
+    constexpr int NXL = (XROWS * 8 + NTt - 1) / NTt;
+    int xseg[NXL], xj[NXL], xdst[NXL];
+    unsigned xcb[NXL];
+    bool xcv[NXL];
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+        const int q = tid + i * NTt, row = q >> 3, c8 = q & 7;
+        xseg[i] = row >= fpr ? 1 : 0;
+        xj[i] = row - xseg[i] * fpr;
+        const int cx = ci0 + c8 * 8;
+        xcv[i] = row < frows && cx < p.C;
+        xcb[i] = (unsigned)cx * 2;
+        xdst[i] = q < XROWS * 8 ? (c8 >> 2) * XHALF + row * 64 + (c8 & 3) * 16 : -1;
+    }
+    u32x4 ra[NPA], rb[NXL];
+    auto gload = [&](int mk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int m = mk + rra + i * RPPA;
+            const unsigned off = (cyv && m < m_end) ? (unsigned)(m - m_begin) * ((unsigned)p.ldy * 2) + cy * 2 : 0xffffffffu;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+        }
+        const int x0 = mk & (p.W - 1), y = (mk >> p.logW) & (p.H - 1);
+        const int frow0 = mk - (y << p.logW) - x0;                 // first row of the frame
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int yy = y + xseg[i] + dyl, xx = x0 + xj[i] - pad;
+            const bool ok = xcv[i] && mk < m_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)(frow0 + (yy << p.logW) + xx - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i]
+                                    : 0xffffffffu;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+        }
+    };
+    const bool do_bias = p.dbias != nullptr && dyl == 0 && tci == 0;   // centre row: the dy tile is tap-independent
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        char* st = &smem[buf * STAGE];
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            *reinterpret_cast<u32x4*>(st + (rra + i * RPPA) * RSA + cka * 16) = ra[i];
+            if (do_bias) {
+                bs[0] += __uint_as_float(ra[i].x << 16); bs[1] += __uint_as_float(ra[i].x & 0xffff0000u);
+                bs[2] += __uint_as_float(ra[i].y << 16); bs[3] += __uint_as_float(ra[i].y & 0xffff0000u);
+                bs[4] += __uint_as_float(ra[i].z << 16); bs[5] += __uint_as_float(ra[i].z & 0xffff0000u);
+                bs[6] += __uint_as_float(ra[i].w << 16); bs[7] += __uint_as_float(ra[i].w & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NXL; ++i)
+            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(st + TA_BYTES + xdst[i]) = RELU ? relu16_bf16(rb[i]) : rb[i];
+    };
+    // fragment addressing (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-channel block)
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int frow = (g16 >> 1) * 8 + (i16 >> 2), fcol2 = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;
+    auto tr2 = [&](const char* lo_, const char* hi_) __attribute__((always_inline)) -> bf16x8 {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_);
+        s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, f);
+    };
+    // footprint row of step pixel pk (before the tap offset): second line of a W = 16 step starts at row fpr
+    int xoffs[2][2];                                             // [k half][lo / hi 4-row block]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            const int pk = kb * 16 + frow + hl * 4;
+            const int fr = segw == 16 ? (pk >> 4) * fpr + (pk & 15) : pk;
+            xoffs[kb][hl] = TA_BYTES + wn * XHALF + fr * 64 + fcol2;
+        }
+    const int aoff = frow * RSA + fcol2 + (wm * 64) * 2;
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+        const char* st = &smem[buf * STAGE];
+        constexpr int NU = 2 * KW;                               // units: (k half, tap), 2 MFMAs each
+        bf16x8 fa[2][2], fb[NU];
+        auto ldA = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const char* pz = st + aoff + kb * 16 * RSA + a * 64;
+                fa[kb][a] = tr2(pz, pz + 4 * RSA);
+            }
+        };
+        auto ldB = [&](int u) __attribute__((always_inline)) {
+            const int kb = u / KW, t = u % KW;
+            fb[u] = tr2(st + xoffs[kb][0] + t * 64, st + xoffs[kb][1] + t * 64);
+        };
+        ldA(0); ldB(0); ldB(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + 2 < NU) ldB(u + 2);
+            if (u == KW - 2) ldA(1);
+            const int kb = u / KW, t = u % KW;
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][0], fb[u], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][1], fb[u], acc[1][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (m_begin < m_end) {
+        gload(m_begin);
+        lstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (int mk = m_begin; mk < m_end; mk += 32, buf ^= 1) {
+            gload(mk + 32);                       // past the slice: out-of-range offsets -> zeros
+            mma(buf);
+            lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    if (do_bias) {
+        float* red = reinterpret_cast<float*>(&smem[0]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
+        __syncthreads();
+        if (tid < CPRA) {
+            for (int k = 0; k < 8; ++k) {
+                float a = 0.f;
+                for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
+                const int co = co0 + tid * 8 + k;
+                if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: 32 x 32 accumulator tiles through a per-wave LDS block
+    float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 32);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[a][t][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int ci = ci0 + wn * 32 + (lane & 31);
+            const int cob = co0 + wm * 64 + a * 32 + (lane >> 5);
+            const int tap = iy * KW + t;
+            if (p.ws) {
+                // partial tile of this row slice: [slice][x-block][tap of the row][BMc][64], plain coalesced stores
+                float* wt = p.ws + (((size_t)bz * gridDim.x + bx) * KW + t) * (size_t)(BMc * 64) +
+                            (size_t)(wm * 64 + a * 32) * 64 + wn * 32;
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j)
+                    wt[(size_t)(2 * j + (lane >> 5)) * 64 + (lane & 31)] = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+            } else if (ci < p.Cin_real) {
+                float* dst = p.dw + ci * p.s_ci + tap * p.s_tap;
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j) {
+                    const int co = cob + 2 * j;
+                    const float v = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+                    if (co < p.Cout && v != 0.f) atomicAdd(dst + co * p.s_co, v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// reduction of the row kernel's partial tiles: dw[co][ci][iy*KW + t] += sum over slices
+struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; };
+__global__ void wgrad_row_reduce_kernel(WgRowRedK p) {
+    const int tile_elems = p.KW * p.BMc * 64;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)p.gx * tile_elems) return;
+    const int bx = (int)(i / tile_elems), e = (int)(i - (long long)bx * tile_elems);
+    const int t = e / (p.BMc * 64), e2 = e - t * (p.BMc * 64);
+    const int r = e2 >> 6, c = e2 & 63;
+    const int tiles = p.tiles_co * p.tiles_ci;
+    const int iy = bx / tiles, rem = bx - iy * tiles;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co = tco * p.BMc + r, ci = tci * 64 + c;
+    if (co >= p.Cout || ci >= p.Cin_real) return;
+    float a = 0.f;
+    for (int z = 0; z < p.nslice; ++z) a += p.ws[((size_t)z * p.gx + bx) * tile_elems + e];
+    p.dw[co * p.s_co + ci * p.s_ci + (iy * p.KW + t) * p.s_tap] += a;
 }
 
 // Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
@@ -1185,7 +1422,8 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
 }
 
 // Validates a weight-gradient request and derives tile shape, grid and row split.
-static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit) {
+// mode: 0 = one tap per workgroup (conv_wgrad_kernel), 1 = one filter row per workgroup (conv_wgrad_row_kernel; ta = WM)
+static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit, int& mode) {
     if (!d || !d->x || !d->dy || !d->dw) return DVD_E_ARG;
     const int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
     if (logH < 0 || logW < 0) return DVD_E_SHAPE;
@@ -1205,6 +1443,13 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         if (d->Cout >= 192) ta = 4;
         else if (d->Cin_real >= 192) tb = 4;
     }
+    static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
+    mode = (use_row && d->dtype == DVD_BF16 && d->kt == 1 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && !d->up2 &&
+            d->W >= 16 && d->Cout >= 96 && d->Cin_real >= 48) ? 1 : 0;
+    if (mode == 1) {   // 256- or 128-channel tile, whichever pads Cout less (256 on a tie)
+        const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
+        ta = w4 <= w2 ? 4 : 2; tb = 1;
+    }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
     { static const int xr = getenv("DVD_WG_XCD") ? atoi(getenv("DVD_WG_XCD")) : 1; p.xcd_remap = xr; }
@@ -1223,8 +1468,9 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
                         // (1536,8192) 267, (3072,4096) 247, (4096,4096) 243, (6144,4096) 242, (8192,2048) 252
         static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 4096;
         static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 4096;
-        const long long base = (long long)p.tiles_co * p.tiles_ci * ntaps;
-        msplit = (tgt + base - 1) / base;
+        static const long long tgt_row = getenv("DVD_WGR_TGT") ? atoll(getenv("DVD_WGR_TGT")) : 2048;
+        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kh : ntaps);
+        msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
         const long long cap = M / minrows > 0 ? M / minrows : 1;
         if (msplit > cap) msplit = cap;
     }
@@ -1238,25 +1484,41 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     if (rows < 32) rows = 32;
     msplit = (M + rows - 1) / rows;
     p.rows_per_split = (int)rows;
-    grid = dim3(p.tiles_co * p.tiles_ci * ntaps, 1, (unsigned)msplit);
+    grid = dim3(p.tiles_co * p.tiles_ci * (mode == 1 ? d->kh : ntaps), 1, (unsigned)msplit);
     return DVD_OK;
 }
 
 extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
-    WgK p; dim3 grid; int ta, tb; long long msplit;
-    if (wgrad_plan(d, p, grid, ta, tb, msplit) != DVD_OK || msplit <= 1) return 0;
+    WgK p; dim3 grid; int ta, tb, mode; long long msplit;
+    if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
+    if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * 64;
     return msplit * (long long)grid.x * (ta * 64) * (tb * 64);
 }
 
 extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
-    WgK p; dim3 grid; int ta, tb; long long msplit;
-    const int rc = wgrad_plan(d, p, grid, ta, tb, msplit);
+    WgK p; dim3 grid; int ta, tb, mode; long long msplit;
+    const int rc = wgrad_plan(d, p, grid, ta, tb, msplit, mode);
     if (rc != DVD_OK) return rc;
     const int ntaps = d->kt * d->kh * d->kw;
     if (d->ws && msplit > 1) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw
     ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) {
+#define LAUNCH_ROW(WM_, KW_)                                                                        \
+        do { if (d->relu_in) conv_wgrad_row_kernel<WM_, KW_, true><<<grid, WM_ * 128, 0, st>>>(p);      \
+             else conv_wgrad_row_kernel<WM_, KW_, false><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
+        if (ta == 4) { if (d->kw == 5) LAUNCH_ROW(4, 5); else LAUNCH_ROW(4, 3); }
+        else         { if (d->kw == 5) LAUNCH_ROW(2, 5); else LAUNCH_ROW(2, 3); }
+#undef LAUNCH_ROW
+        if (p.ws) {
+            WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, d->kw, p.Cout, p.Cin_real,
+                        p.s_co, p.s_ci, p.s_tap};
+            const long long n = (long long)grid.x * r.KW * r.BMc * 64;
+            wgrad_row_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(r);
+        }
+        return launch_status();
+    }
     if (d->dtype == DVD_BF16) {
         if (ta == 4) conv_wgrad_kernel<bf16_t, 4, 2><<<grid, NT, 0, st>>>(p);
         else if (tb == 4) conv_wgrad_kernel<bf16_t, 2, 4><<<grid, NT, 0, st>>>(p);

@@ -50,6 +50,10 @@ CASES = [
     (1, 8, 16, (4, 16, 16), (3, 3, 3), False, False),  # 3-D: footprint from frame t+dt
     (32, 16, 40, (64, 64), (5, 5), False, True),     # 512 tiles of 256 x 128: the 16 x 16 patch variant
     (16, 40, 264, (64, 64), (5, 5), False, False),   # 8-wave 256 x 256 variant, 5x5, ragged N
+    # filter-row weight-gradient kernel (Cout >= 96, Cin >= 48, W >= 16)
+    (3, 72, 136, (16, 16), (5, 5), False, False),    # W = 16: a 32-pixel step is two lines; 128-channel tile, ragged
+    (2, 64, 200, (32, 32), (3, 3), False, True),     # 256-channel tile, 3 taps per row, ReLU on the staged input
+    (2, 56, 264, (16, 64), (5, 5), False, False),    # W = 64: two segments per line; 2 x 1 tiles, ragged both ways
 ]
 
 
