@@ -1018,12 +1018,13 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
         bz = lp / gx; bx = lp - bz * gx;
     }
     const int tiles = p.tiles_co * p.tiles_ci;
-    const int iy = bx / tiles;
-    const int rem = bx - iy * tiles;
+    const int irow = bx / tiles;                                 // filter row index: it * kh + iy
+    const int rem = bx - irow * tiles;
     const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
     const int co0 = tco * BMc, ci0 = tci * 64;
     constexpr int pad = KW >> 1;
-    const int dyl = iy - pad;
+    const int it = irow / KW, iy = irow - it * KW;               // kh == kw
+    const int dyl = iy - pad, dtl = it - (p.kt >> 1);
     const int m_begin = bz * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
@@ -1073,17 +1074,23 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
         }
         const int x0 = mk & (p.W - 1), y = (mk >> p.logW) & (p.H - 1);
-        const int frow0 = mk - (y << p.logW) - x0;                 // first row of the frame
+        int frow0 = mk - (y << p.logW) - x0;                       // first row of the frame
+        bool tok = mk < m_end;
+        if (p.kt > 1) {                                            // 3-D: the footprint comes from frame t + dt
+            const int tt = (mk >> (p.logW + p.logH)) % p.T + dtl;
+            tok = tok && (unsigned)tt < (unsigned)p.T;
+            frow0 += dtl << (p.logW + p.logH);
+        }
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             const int yy = y + xseg[i] + dyl, xx = x0 + xj[i] - pad;
-            const bool ok = xcv[i] && mk < m_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const bool ok = xcv[i] && tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
             const unsigned off = ok ? (unsigned)(frow0 + (yy << p.logW) + xx - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i]
                                     : 0xffffffffu;
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
         }
     };
-    const bool do_bias = p.dbias != nullptr && dyl == 0 && tci == 0;   // centre row: the dy tile is tap-independent
+    const bool do_bias = p.dbias != nullptr && dyl == 0 && dtl == 0 && tci == 0;   // centre row: the dy tile is tap-independent
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto lstore = [&](int buf) __attribute__((always_inline)) {
         char* st = &smem[buf * STAGE];
@@ -1190,7 +1197,7 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
             __builtin_amdgcn_wave_barrier();
             const int ci = ci0 + wn * 32 + (lane & 31);
             const int cob = co0 + wm * 64 + a * 32 + (lane >> 5);
-            const int tap = iy * KW + t;
+            const int tap = irow * KW + t;
             if (p.ws) {
                 // partial tile of this row slice: [slice][x-block][tap of the row][BMc][64], plain coalesced stores
                 float* wt = p.ws + (((size_t)bz * gridDim.x + bx) * KW + t) * (size_t)(BMc * 64) +
@@ -1444,11 +1451,10 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         else if (d->Cin_real >= 192) tb = 4;
     }
     static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
-    mode = (use_row && d->dtype == DVD_BF16 && d->kt == 1 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && !d->up2 &&
-            d->W >= 16 && d->Cout >= 96 && d->Cin_real >= 48) ? 1 : 0;
-    if (mode == 1) {   // 256- or 128-channel tile, whichever pads Cout less (256 on a tie)
+    mode = (use_row && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && !d->up2 && d->W >= 16) ? 1 : 0;
+    if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
         const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
-        ta = w4 <= w2 ? 4 : 2; tb = 1;
+        ta = d->Cout <= 64 ? 1 : (w4 <= w2 ? 4 : 2); tb = 1;
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
@@ -1469,7 +1475,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 4096;
         static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 4096;
         static const long long tgt_row = getenv("DVD_WGR_TGT") ? atoll(getenv("DVD_WGR_TGT")) : 2048;
-        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kh : ntaps);
+        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps);
         msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
         const long long cap = M / minrows > 0 ? M / minrows : 1;
         if (msplit > cap) msplit = cap;
@@ -1484,7 +1490,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     if (rows < 32) rows = 32;
     msplit = (M + rows - 1) / rows;
     p.rows_per_split = (int)rows;
-    grid = dim3(p.tiles_co * p.tiles_ci * (mode == 1 ? d->kh : ntaps), 1, (unsigned)msplit);
+    grid = dim3(p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps), 1, (unsigned)msplit);
     return DVD_OK;
 }
 
@@ -1508,8 +1514,9 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
 #define LAUNCH_ROW(WM_, KW_)                                                                        \
         do { if (d->relu_in) conv_wgrad_row_kernel<WM_, KW_, true><<<grid, WM_ * 128, 0, st>>>(p);      \
              else conv_wgrad_row_kernel<WM_, KW_, false><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
-        if (ta == 4) { if (d->kw == 5) LAUNCH_ROW(4, 5); else LAUNCH_ROW(4, 3); }
-        else         { if (d->kw == 5) LAUNCH_ROW(2, 5); else LAUNCH_ROW(2, 3); }
+        if (ta == 4)      { if (d->kw == 5) LAUNCH_ROW(4, 5); else LAUNCH_ROW(4, 3); }
+        else if (ta == 2) { if (d->kw == 5) LAUNCH_ROW(2, 5); else LAUNCH_ROW(2, 3); }
+        else              { if (d->kw == 5) LAUNCH_ROW(1, 5); else LAUNCH_ROW(1, 3); }
 #undef LAUNCH_ROW
         if (p.ws) {
             WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, d->kw, p.Cout, p.Cin_real,
