@@ -997,14 +997,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
 // MFMA drop from 384 (256 x 128 tile, one tap) to ~130, and dy / x are fetched from L2 KH instead of KH*KW times.
 //   waves: WM (64 out-channels each) x 2 (32 in-channels each); wave tile 64 x (KW taps x 32) = 2 x KW accumulators
 //   LDS:   dy [32 rows][64*WM ch] (+64 B pad, transposing reads as in conv_wgrad_kernel);
-//          x  [2 halves of 32 ch][40 rows][64 B]: the 4 consecutive rows a ds_read_b64_tr_b16 pass touches are
+//          x  [2 halves of 32 ch][48 rows][64 B]: the 4 consecutive rows a ds_read_b64_tr_b16 pass touches are
 //             256 contiguous bytes (conflict-free without a swizzle) and a tap is a +64-byte immediate offset.
 template <int WM, int KW, bool RELU>
 __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
     constexpr int NTt = WM * 128, BMc = WM * 64;
     constexpr int RSA = BMc * 2 + 64;
     constexpr int TA_BYTES = 32 * RSA;
-    constexpr int XROWS = 40, XHALF = XROWS * 64, TB_BYTES = 2 * XHALF;
+    constexpr int XROWS = 48, XHALF = XROWS * 64, TB_BYTES = 2 * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows
     constexpr int STAGE = TA_BYTES + TB_BYTES;
     constexpr int EPIB = WM * 2 * 32 * 32 * 4;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE > EPIB ? 2 * STAGE : EPIB];
@@ -1043,8 +1043,8 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
         (void*)(p.x + xbase_b), 0, xleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)xleft, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.dy + ybase_b), 0, yleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)yleft, 0x00020000);
-    // step geometry: 32 pixels = one 32-pixel segment of a line (W >= 32) or two 16-pixel lines (W = 16)
-    const int segw = min(p.W, 32), fpr = segw + KW - 1, frows = (32 / segw) * fpr;
+    // step geometry: 32 pixels = one 32-pixel segment of a line (W >= 32), two 16-pixel lines or four 8-pixel lines
+    const int segw = min(p.W, 32), logsegw = min(p.logW, 5), fpr = segw + KW - 1, frows = (32 >> logsegw) * fpr;
     // dy loader: NPA 16-byte chunks per thread
     constexpr int CPRA = BMc / 8, RPPA = NTt / CPRA, NPA = 32 / RPPA;
     const int rra = tid / CPRA, cka = tid % CPRA;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
         const int q = tid + i * NTt, row = q >> 3, c8 = q & 7;
-        xseg[i] = row >= fpr ? 1 : 0;
+        xseg[i] = row / fpr;
         xj[i] = row - xseg[i] * fpr;
         const int cx = ci0 + c8 * 8;
         xcv[i] = row < frows && cx < p.C;
@@ -1119,14 +1119,14 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
         s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, f);
     };
-    // footprint row of step pixel pk (before the tap offset): second line of a W = 16 step starts at row fpr
+    // footprint row of step pixel pk (before the tap offset): line s of a multi-line step starts at row s * fpr
     int xoffs[2][2];                                             // [k half][lo / hi 4-row block]
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
             const int pk = kb * 16 + frow + hl * 4;
-            const int fr = segw == 16 ? (pk >> 4) * fpr + (pk & 15) : pk;
+            const int fr = (pk >> logsegw) * fpr + (pk & (segw - 1));
             xoffs[kb][hl] = TA_BYTES + wn * XHALF + fr * 64 + fcol2;
         }
     const int aoff = frow * RSA + fcol2 + (wm * 64) * 2;
@@ -1451,7 +1451,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         else if (d->Cin_real >= 192) tb = 4;
     }
     static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
-    mode = (use_row && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && !d->up2 && d->W >= 16) ? 1 : 0;
+    mode = (use_row && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && !d->up2 && d->W >= 8 && (d->H * d->W) % 32 == 0) ? 1 : 0;
     if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
         const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
         ta = d->Cout <= 64 ? 1 : (w4 <= w2 ? 4 : 2); tb = 1;

@@ -15,4 +15,4 @@ print(f"{'kind':>4} {'M':>9} {'C':>5} {'Cout':>5} {'taps':>4} {'split':>5} {'flg
 for key, r in sorted(rows.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     print(f"{key[0]:>4} {key[1]:>9} {key[2]:>5} {key[3]:>5} {key[4]:>4} {key[5]:>5} {key[6]:>3} {r[0]:>5} {r[1]:>9.2f} {100 * r[1] / tot:>5.1f} "
           f"{r[2] / (r[1] * 1e-3) / 1e12 if r[1] else 0:>7.1f} {1e3 * r[1] / r[0]:>9.1f}")
-print("total ms", round(tot, 1))
+print("total ms", round(tot, 1), " by kind:", {k: round(sum(r[1] for kk, r in rows.items() if kk[0] == k), 1) for k in sorted({kk[0] for kk in rows})})
