@@ -14,7 +14,8 @@ cnt = collections.Counter()
 for path in sorted(glob.glob(f"{pmc_dir}/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(path)):
         kn = r["Kernel_Name"]
-        k = "conv_igemm" if "conv_igemm" in kn else "conv_wgrad" if "conv_wgrad" in kn else "other"
+        # forward / backward-data family = halo-staged + tap-by-tap kernels; weight-gradient family = row + tap kernels
+        k = "conv_igemm" if ("conv_igemm" in kn or "conv_halo" in kn) else "conv_wgrad" if "conv_wgrad" in kn else "other"
         agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
 out = {"source": "rocprofv3 -i tools/pmc_traffic.txt (separate passes: FETCH_SIZE, then WRITE_SIZE) --kernel-trace -- python "
