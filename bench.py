@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_GFLOP_PER_CLIP = {(32, 48, 64): 8148.5}       # SURVEY.md section 8(d) / BASELINE.md section 3
+F_GFLOP_PER_CLIP = {(32, 48, 64): 8148.5, (32, 48, 128): 32608.6}       # SURVEY.md section 8(d) / BASELINE.md section 3
 PEAK_BF16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=48)
     ap.add_argument("--k-sample", type=int, default=8)
     ap.add_argument("--n-class", type=int, default=101)
+    ap.add_argument("--size", type=int, default=64, choices=[64, 128],
+                    help="frame size; 128 = the Kinetics-600-shaped clips of BASELINE configs[3] (use --n-class 600 and a --batch that fits)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-prof", action="store_true")
@@ -72,18 +74,18 @@ def cpu_baseline(a):
     torch.manual_seed(0)
     B = 2
     sds = []
-    for net in (Generator(120, 4, a.n_class, a.ch, a.frames), SpatialDiscriminator(a.ch, a.n_class),
+    for net in (Generator(120, a.size // 16, a.n_class, a.ch, a.frames), SpatialDiscriminator(a.ch, a.n_class),
                 TemporalDiscriminator(a.ch, a.n_class)):
         sds.append(O.make_state({k: v.detach().clone() for k, v in net.state_dict().items()}))
-    st = O.TrainState(*sds, ch=a.ch, n_frames=a.frames, k_sample=a.k_sample, n_class=a.n_class)
-    real = torch.rand(B, 3, a.frames, 64, 64) * 2 - 1
+    st = O.TrainState(*sds, ch=a.ch, n_frames=a.frames, k_sample=a.k_sample, n_class=a.n_class, latent_dim=a.size // 16)
+    real = torch.rand(B, 3, a.frames, a.size, a.size) * 2 - 1
     labels = torch.randint(0, a.n_class, (B,))
     t0 = time.time()
     O.train_step(st, real, labels, torch.randn(B, 120), torch.randint(0, a.n_class, (B,)),
                  torch.randperm(a.frames), torch.randperm(a.frames))
     dt = time.time() - t0
     return {"value": round(B / dt, 5), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"1 full G+Ds+Dt step (no warm-up), B={B}, T={a.frames}, 64x64, ch={a.ch} (fp32 torch CPU ops), {dt:.1f} s"}
+            "sample": f"1 full G+Ds+Dt step (no warm-up), B={B}, T={a.frames}, {a.size}x{a.size}, ch={a.ch} (fp32 torch CPU ops), {dt:.1f} s"}
 
 
 def main():
@@ -100,11 +102,11 @@ def main():
                              lr_schr="const", total_epoch=1, d_iters=1, batch_size=a.batch, g_lr=5e-5, d_lr=5e-5,
                              beta1=0.0, beta2=0.9, n_class=a.n_class, k_sample=a.k_sample)
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    tr = Trainer([], cfg, device=dev, compute_dtype=dtype)
+    tr = Trainer([], cfg, device=dev, compute_dtype=dtype, latent_dim=a.size // 16)
     tr.G.train(); tr.D_s.train(); tr.D_t.train()
     gen = torch.Generator().manual_seed(1)
     gB = a.batch * world
-    real = D.shard(torch.rand(gB, 3, a.frames, 64, 64, generator=gen) * 2 - 1, rank, world).to(dev)
+    real = D.shard(torch.rand(gB, 3, a.frames, a.size, a.size, generator=gen) * 2 - 1, rank, world).to(dev)
     labels = D.shard(torch.randint(0, a.n_class, (gB,), generator=gen), rank, world).to(dev)
     torch.manual_seed(100 + rank)                          # per-rank z / labels, shared frame ids do not matter here
 
@@ -143,7 +145,7 @@ def main():
             res[name] = {"launches": int(n), "ms": tms.value,
                          "tflops": (fl.value / (tms.value * 1e-3) / 1e12) if tms.value else 0.0,
                          "avg_us": tms.value * 1e3 / max(n, 1), "gflop_per_launch": fl.value / max(n, 1) / 1e9}
-        F = F_GFLOP_PER_CLIP.get((a.ch, a.frames, 64))
+        F = F_GFLOP_PER_CLIP.get((a.ch, a.frames, a.size))
         dom = res["conv_igemm"]
         roof = {"bound": "mfma", "kernel": "conv_halo_kernel + conv_igemm_kernel <bf16> (forward + backward-data convolutions)" if a.dtype == "bf16" else "conv_halo_kernel + conv_igemm_kernel <f32>",
                 "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -154,11 +156,11 @@ def main():
                 "step_achieved": round(value / world * F / 1e3, 1) if F else None,
                 "step_frac": round(value / world * F / 1e3 / PEAK_BF16_TFLOPS, 4) if F else None}
     if rank == 0:
-        out = {"metric": "clips/sec per G+Ds+Dt step, 48x64x64 UCF-101 synth", "value": round(value, 3), "unit": "clips/s",
+        out = {"metric": "clips/sec per G+Ds+Dt step, 48x64x64 UCF-101 synth" if a.size == 64 else f"clips/sec per G+Ds+Dt step, {a.frames}x{a.size}x{a.size} Kinetics-600-shaped synth", "value": round(value, 3), "unit": "clips/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": f"UCF-101-shaped 101-class {a.frames}x64x64 clips, G+Ds+Dt hinge step, ch={a.ch}, "
-                                      f"k_sample={a.k_sample}, batch {a.batch}/GPU (BASELINE configs[1])",
+               "config": {"workload": f"{'UCF-101' if a.size == 64 else 'Kinetics-600'}-shaped {a.n_class}-class {a.frames}x{a.size}x{a.size} clips, G+Ds+Dt hinge step, ch={a.ch}, "
+                                      f"k_sample={a.k_sample}, batch {a.batch}/GPU (BASELINE configs[{1 if a.size == 64 else 3}])",
                           "global_batch": gB, "parallelism": f"dp{world}"},
                "losses": [round(v, 4) for v in lossv],
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}

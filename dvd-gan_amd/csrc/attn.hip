@@ -9,7 +9,8 @@
 
 namespace {
 
-constexpr int QB = 16;      // query rows per workgroup
+// QB = query rows per workgroup (template parameter: 16, or 8 when 16 rows of scores do not fit 64 KB of LDS --
+// N = 1024 tokens, the 128 x 128 configuration)
 
 __device__ float blk_sum(float v, float* sh) {
     v = wave_sum(v);
@@ -22,7 +23,7 @@ __device__ float blk_sum(float v, float* sh) {
     return t;
 }
 
-template <typename T>
+template <typename T, int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* x,
                                                        int ldx, int C, const float* gamma, T* y, T* att_out,
                                                        float* A, int N) {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, in
 }
 
 // Backward, row pass: dA, dS (written over `dS` [F][N][N]), dq, dgamma.
-template <typename T>
+template <typename T, int QB>
 __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* dy,
                                                             int ldx, int C, const float* gamma, const T* att_out,
                                                             const float* A, float* dS, T* dqkv, float* dgamma, int N) {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ld
 }
 
 // Backward, column pass: dv[j][c] = gamma * sum_i A[i][j] dy[i][c];  dk[j][d] = sum_i dS[i][j] q[i][d]
-template <typename T>
+template <typename T, int QB>
 __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* dy,
                                                             int ldx, int C, const float* gamma, const float* A,
                                                             const float* dS, T* dqkv, int N) {
@@ -207,11 +208,15 @@ extern "C" int dvd_attention_forward(int dtype, const void* qkv, int ldq, int dq
                                      int ldx, int C, const float* gamma, void* y, void* att_out, float* A,
                                      long long frames, int N, void* stream) {
     if (!qkv || !x || !gamma || !y || frames <= 0 || N <= 0 || dq <= 0 || C <= 0) return DVD_E_ARG;
-    if ((size_t)QB * N * sizeof(float) > 64 * 1024 || frames > 65535) return DVD_E_SHAPE;
-    dim3 grid(cdiv(N, QB), (unsigned)frames);
-    const size_t sh = (size_t)QB * N * sizeof(float);
-    BY_DTYPE(dtype, attn_fwd_kernel<T><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)x, ldx, C, gamma,
-                                                              (T*)y, (T*)att_out, A, N));
+    if (frames > 65535) return DVD_E_SHAPE;
+    const int qb = (size_t)16 * N * sizeof(float) <= 64 * 1024 ? 16 : 8;
+    if ((size_t)qb * N * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    dim3 grid(cdiv(N, qb), (unsigned)frames);
+    const size_t sh = (size_t)qb * N * sizeof(float);
+#define ATT_FWD(QB_) BY_DTYPE(dtype, attn_fwd_kernel<T, QB_><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, \
+                                       (const T*)x, ldx, C, gamma, (T*)y, (T*)att_out, A, N))
+    if (qb == 16) ATT_FWD(16); else ATT_FWD(8);
+#undef ATT_FWD
     return launch_status();
 }
 
@@ -219,14 +224,20 @@ extern "C" int dvd_attention_backward(int dtype, const void* qkv, int ldq, int d
                                       int ldx, int C, const float* gamma, const void* att_out, const float* A,
                                       float* dS, void* dqkv, float* dgamma, long long frames, int N, void* stream) {
     if (!qkv || !dy || !gamma || !att_out || !A || !dS || !dqkv || frames <= 0 || N <= 0) return DVD_E_ARG;
-    if ((size_t)QB * (N + C) * sizeof(float) > 64 * 1024 || frames > 65535) return DVD_E_SHAPE;
-    dim3 grid(cdiv(N, QB), (unsigned)frames);
-    const size_t sh = (size_t)QB * N * sizeof(float);
-    if (C & 7) return DVD_E_SHAPE;
-    const size_t sh_rows = sh + (size_t)QB * C * sizeof(float);
-    BY_DTYPE(dtype, attn_bwd_rows_kernel<T><<<grid, 256, sh_rows, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)dy, ldx, C,
-                                                                   gamma, (const T*)att_out, A, dS, (T*)dqkv, dgamma, N));
-    BY_DTYPE(dtype, attn_bwd_cols_kernel<T><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, (const T*)dy, ldx, C,
-                                                                   gamma, A, dS, (T*)dqkv, N));
+    if (frames > 65535 || (C & 7)) return DVD_E_SHAPE;
+    const int qb = (size_t)16 * (N + C) * sizeof(float) <= 64 * 1024 ? 16 : 8;
+    if ((size_t)qb * (N + C) * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    dim3 grid(cdiv(N, qb), (unsigned)frames);
+    const size_t sh = (size_t)qb * N * sizeof(float);
+    const size_t sh_rows = sh + (size_t)qb * C * sizeof(float);
+#define ATT_BWD(QB_)                                                                                                  \
+    do {                                                                                                              \
+        BY_DTYPE(dtype, attn_bwd_rows_kernel<T, QB_><<<grid, 256, sh_rows, S_>>>((const T*)qkv, ldq, dq, koff, voff,  \
+                            (const T*)dy, ldx, C, gamma, (const T*)att_out, A, dS, (T*)dqkv, dgamma, N));             \
+        BY_DTYPE(dtype, attn_bwd_cols_kernel<T, QB_><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff,       \
+                            (const T*)dy, ldx, C, gamma, A, dS, (T*)dqkv, N));                                        \
+    } while (0)
+    if (qb == 16) ATT_BWD(16); else ATT_BWD(8);
+#undef ATT_BWD
     return launch_status();
 }

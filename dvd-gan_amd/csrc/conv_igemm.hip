@@ -1,16 +1,19 @@
-// Implicit-GEMM convolution (forward / backward-data) and backward-weight for gfx950.
+// Convolutions of the DVD-GAN step for gfx950: forward / backward-data (implicit GEMM, no im2col) and
+// backward-weight, bf16 MFMA with fp32 accumulation or exact fp32 MFMA.
 //
-// One workgroup = 256 threads = 4 waves computes a 128 x 128 output tile; each wave owns a
-// 64 x 64 quadrant as 2 x 2 MFMA 32x32 tiles (64 fp32 accumulator registers).  K is walked tap by
-// tap in 64-byte channel chunks (32 bf16 / 16 f32): the activation tile is GATHERED from the
-// channels-last tensor (shifted rows, zero outside the frame, optional nearest-x2 index map and
-// ReLU), so no im2col buffer ever exists.  Global -> registers -> LDS staging, two LDS buffers,
-// one barrier per K step; LDS rows are 64 B data + 16 B pad (80 B) which makes the ds_read_b128
-// fragment reads bank-conflict free.
+//   conv_halo_kernel       3x3 / 5x5 / 3x3x3 filters on frames >= 16 pixels wide: the input footprint of a
+//                          16 x 16 pixel patch is staged in LDS once per channel chunk (LDS-DMA), every tap
+//                          reads it at an immediate offset; only the weight tile moves per tap.
+//   conv_igemm_kernel      1x1 filters and narrow frames: activation tile gathered per (chunk, tap).
+//   conv_wgrad_row_kernel  weight gradients, one filter row (all KW taps) per workgroup, reduction over pixels
+//                          through transposing LDS reads (ds_read_b64_tr_b16).
+//   conv_wgrad_kernel      weight gradients, one tap per workgroup (1x1, upsampling convs, fp32 mode).
 //
 //   bf16 : v_mfma_f32_32x32x16_bf16   (A: lane l holds row l&31, k = 8*(l>>5)..+7)
 //   f32  : v_mfma_f32_32x32x2_f32     (A: lane l holds row l&31, k = l>>5)        exact mode
 //   C/D  : col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// Environment switches read here are for A/B measurements only (DVD_CONV_HALO, DVD_WG_ROW, DVD_WG_TGT, ...);
+// none of them changes results.
 #include "common.h"
 
 namespace {
@@ -81,7 +84,6 @@ struct ConvK {
     int up2, relu_in, act, out_f32;
     size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
     int maxshift;                        // largest |tap shift| in rows
-    int dbg;                             // timing experiments only (DVD_CONV_DBG), 0 in production
     GruEpi g;                            // optional fused ConvGRU gate epilogue (mode 0 = off)
 };
 
@@ -318,9 +320,6 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         // wave-uniform part of the offset: tap shift + channel chunk
         const unsigned udelta_ = (unsigned)(((dt_ * p.H + dy_) * p.W + dx_) * (int)ldb + cc * 64);
         char* abase_ = &smem[buf][wu * 1024];
-        const bool skipA_ = p.dbg == 2 || (p.dbg == 3 && tap != 0);
-        const bool oobA_ = p.dbg == 1 || (p.dbg == 4 && tap != 0);
-        if (!skipA_)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_, tt_ = at[i] + dt_;
@@ -331,13 +330,12 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
                 const int f_ = am[i] >> (p.logW + p.logH);
                 off_ = (unsigned)(((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1) - base_row) * ldb + cc * 64 + q * 16;
             }
-            dma16(rin, abase_ + i * (NWAVE * 1024), (ok_ && !oobA_) ? off_ : 0xffffffffu);
+            dma16(rin, abase_ + i * (NWAVE * 1024), ok_ ? off_ : 0xffffffffu);
         }
         const unsigned uw_ = (unsigned)(tap * p.Cout) * (unsigned)p.C * (unsigned)esz + cc * 64;
         char* bbase_ = &smem[buf][ABYTES + wu * 1024];
-        if (p.dbg != 2)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_ && p.dbg != 1) ? woff[j] + uw_ : 0xffffffffu);
+        for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_) ? woff[j] + uw_ : 0xffffffffu);
         ++tap;
         if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
         if (tap == ntaps) { tap = 0; it = 0; iy = 0; ix = 0; ++cc; }
@@ -370,7 +368,7 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         }
         __builtin_amdgcn_s_barrier();
         int st = 0, st2 = 2;                                   // stage of tile s, stage of tile s+2
-        const bool late = WN == 4 && wu >= NWAVE / 2 && !(p.dbg & 8);
+        const bool late = WN == 4 && wu >= NWAVE / 2;
         for (int sidx = 0; sidx < nsteps; ++sidx) {
             const bool issue = sidx + 2 < nsteps;
             // 8-wave tiles put two waves on every SIMD: the second half issues its DMAs AFTER its MFMAs,
@@ -700,7 +698,7 @@ struct WgK {
     int tiles_co, tiles_ci, rows_per_split;
     long long s_co, s_ci, s_tap;
     size_t x_bytes, dy_bytes;
-    int maxshift, xcd_remap, skip_epi;
+    int maxshift, xcd_remap;
     float* dbias;
     float* ws;                           // partial tiles [slice][x-block][BMc*BNc] when non-null
 };
@@ -982,7 +980,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
                 for (int j = 0; j < 16; ++j) {
                     const int co = cob + 2 * j;
                     const float v = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
-                    if (co < p.Cout && v != 0.f && !p.skip_epi) atomicAdd(dst + co * p.s_co, v);
+                    if (co < p.Cout && v != 0.f) atomicAdd(dst + co * p.s_co, v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1390,7 +1388,6 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         if (wb >= 0xffffffffull) return DVD_E_SHAPE;
         p.in_bytes = inb; p.w_bytes = (unsigned)wb;
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
-        { static const int dbg = getenv("DVD_CONV_DBG") ? atoi(getenv("DVD_CONV_DBG")) : 0; p.dbg = dbg; }
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= 512;   // >= 2 workgroups per CU
@@ -1454,12 +1451,13 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     mode = (use_row && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && !d->up2 && d->W >= 8 && (d->H * d->W) % 32 == 0) ? 1 : 0;
     if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
         const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
+        static const int force_wm = getenv("DVD_WGR_WM") ? atoi(getenv("DVD_WGR_WM")) : 0;
         ta = d->Cout <= 64 ? 1 : (w4 <= w2 ? 4 : 2); tb = 1;
+        if (force_wm && ta > force_wm) ta = force_wm;
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
     { static const int xr = getenv("DVD_WG_XCD") ? atoi(getenv("DVD_WG_XCD")) : 1; p.xcd_remap = xr; }
-    { static const int se = getenv("DVD_WG_SKIPEPI") ? atoi(getenv("DVD_WG_SKIPEPI")) : 0; p.skip_epi = se; }
     {
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
         const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;

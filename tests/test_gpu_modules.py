@@ -270,3 +270,38 @@ def test_convgru_large_rows_uses_fused_gate_epilogue(dtype):
     with torch.no_grad():
         got = ncl(cell.run(cl(xs.reshape(T * B, cin, S, S).to(DEV), dtype), T, False), hid).view(T, B, hid, S, S)
     assert rel(got, want) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] frame size (128 x 128)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_discriminators_at_128x128_frames(dtype):
+    """Kinetics-600-shaped clips (48 x 128 x 128, BASELINE configs[3]) put D_s's self-attention at N = 1024 tokens:
+    16 query rows of scores + dy no longer fit 64 KB of LDS and the attention kernels switch to 8-row blocks
+    (csrc/attn.hip).  No golden exists at this size (the reference needs ~minutes per step here), so the check is
+    against the CPU oracle on the same weights: D_s forward + input gradient, D_t forward."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.disc_nets import SpatialDiscriminator, TemporalDiscriminator
+    torch.manual_seed(5)
+    B, k, T = 2, 2, 8
+    Ds = SpatialDiscriminator(2, 3, compute_dtype=dtype)
+    with torch.no_grad():
+        Ds.attn.gamma.fill_(0.7)                      # gamma = 0 at init would hide the attention path
+    sd = O.make_state({kk: v.detach().clone() for kk, v in Ds.state_dict().items()}, requires_grad=False)
+    x = torch.rand(B, k, 3, 128, 128) * 2 - 1
+    cls = torch.tensor([0, 2])
+    xr = x.clone().requires_grad_(True)
+    want = O.spatial_disc(sd, xr, cls)
+    gy = torch.randn(want.shape)
+    want.backward(gy)
+    Ds = Ds.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    got = Ds(xg, cls.to(DEV))
+    ft, gt = {torch.float32: (2e-4, 1e-3), torch.bfloat16: (3e-2, 0.1)}[dtype]
+    assert rel(got, want.detach()) < ft
+    got.backward(gy.to(DEV))
+    assert rel(xg.grad, xr.grad) < gt
+    Dt = TemporalDiscriminator(2, 3, compute_dtype=dtype)
+    sdt = O.make_state({kk: v.detach().clone() for kk, v in Dt.state_dict().items()}, requires_grad=False)
+    v = torch.rand(B, 3, T, 64, 64) * 2 - 1                   # vid_downsample of 128 x 128 frames
+    with torch.no_grad():
+        assert rel(Dt.to(DEV)(v.to(DEV), cls.to(DEV)), O.temporal_disc(sdt, v, cls)) < ft

@@ -132,3 +132,27 @@ def test_adam_kernel_matches_torch():
         opt.step()
         K.adam_step(p, gr.to(DEV), m, v, 2e-3, 0.0, 0.9, 1e-8, step)
         assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6
+
+
+def test_step_at_128x128_frames_matches_oracle():
+    """BASELINE configs[3] frame size (latent_dim = 8 -> 128 x 128 clips): one hinge step at ch=2, T=8, k=4, B=2 in
+    exact mode against the CPU oracle on the same weights, inputs and RNG draws.  Exercises the 128-wide GResBlock /
+    colorize convs, D_s attention at 1024 tokens (8-row attention blocks) and D_t on 64 x 64 pooled frames."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.train_step import Trainer
+    torch.manual_seed(13)
+    ch, T, k, B, ncls, zd, ld = 2, 8, 4, 2, 3, 16, 8
+    cfg = argparse.Namespace(adv_loss="hinge", z_dim=zd, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
+                             total_epoch=1, d_iters=1, batch_size=B, g_lr=5e-5, d_lr=5e-5, beta1=0.0, beta2=0.9,
+                             n_class=ncls, k_sample=k)
+    tr = Trainer([], cfg, device=torch.device("cuda", 0), compute_dtype=torch.float32, latent_dim=ld)
+    sds = [O.make_state({kk: v.detach().cpu().clone() for kk, v in net.state_dict().items()})
+           for net in (tr.G, tr.D_s, tr.D_t)]
+    st = O.TrainState(*sds, ch=ch, n_frames=T, k_sample=k, n_class=ncls, z_dim=zd, latent_dim=ld)
+    real = torch.rand(B, 3, T, 128, 128) * 2 - 1
+    labels = torch.randint(0, ncls, (B,))
+    draws = {"perm_real": torch.randperm(T), "z": torch.randn(B, zd), "z_class": torch.randint(0, ncls, (B,)),
+             "perm_fake": torch.randperm(T)}
+    got = [float(v.detach()) for v in tr.train_step(real, labels, draws)]
+    want = O.train_step(st, real, labels, draws["z"], draws["z_class"], draws["perm_real"], draws["perm_fake"])
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
