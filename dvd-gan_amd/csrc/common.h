@@ -83,7 +83,8 @@ template <typename T> __device__ __forceinline__ float round_to(float v) { retur
 template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
 // Internal (not part of the public ABI): ConvGRU gate math fused into the convolution epilogue, used
-// by gru.hip when the recurrent conv needs no split-K.  mode 1: [u|r] conv, mode 2: out-gate conv.
+// by gru.hip when the recurrent conv needs no split-K.  mode 1: [u|r] conv, mode 2: out-gate conv (forward);
+// mode 3: d(h*r) conv of the backward pass (r, hprev, h32n = fp32 carry, o = dg base), mode 4: carry += conv.
 struct GruEpi {
     int mode, h, ldg;
     const void* gx; const void* hprev; const float* h32p; const void* u_in;

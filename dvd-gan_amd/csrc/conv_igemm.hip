@@ -193,6 +193,28 @@ __device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, in
         if (p.g.h32n) store8<float>(p.g.h32n + o, hp);
         return;
     }
+    if (p.g.mode == 3) {            // BPTT: acc = d(h*r);  carry += acc*r;  d(pre_r) = acc*h_prev*r(1-r)   (gru.hip gru_bwd_r)
+        const int h = p.g.h;
+        const size_t o = (size_t)row * h + col;
+        float rr[8], hp[8], cy[8];
+        load8<T>(reinterpret_cast<const T*>(p.g.r) + o, rr);
+        load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
+        load8<float>(p.g.h32n + o, cy);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { cy[k] += v[k] * rr[k]; v[k] = v[k] * hp[k] * rr[k] * (1.f - rr[k]); }
+        store8<float>(p.g.h32n + o, cy);
+        store8<T>(reinterpret_cast<T*>(p.g.o) + (size_t)row * p.g.ldg + h + col, v);
+        return;
+    }
+    if (p.g.mode == 4) {            // BPTT: carry += acc  (dh contribution of the [u|r] backward-data conv)
+        const size_t o = (size_t)row * p.g.h + col;
+        float cy[8];
+        load8<float>(p.g.h32n + o, cy);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cy[k] += v[k];
+        store8<float>(p.g.h32n + o, cy);
+        return;
+    }
     if (p.ws) {                                                    // raw split-K partial sums
         float* dst = p.ws + ((size_t)z * p.M + row) * p.Cout + col;
         if (nvalid == 8 && !(p.Cout & 3)) {

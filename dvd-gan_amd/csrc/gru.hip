@@ -177,6 +177,15 @@ int conv_fused(int dtype, int B, int H, int W, int k, const void* in, int C, con
     return dvd_conv_forward_gru(&d, &g, stream);
 }
 
+// backward-data conv of the BPTT whose epilogue folds the result into the carry / gate gradients (modes 3, 4)
+int conv_fused_bwd(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, int Cout,
+                   const GruEpi& g, void* stream) {
+    dvd_conv_desc d = {};
+    d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = ldi; d.Cout = Cout; d.ldo = Cout;
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.out = g.h32n;     // `out` itself is not written
+    return dvd_conv_forward_gru(&d, &g, stream);
+}
+
 int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, int Cout,
                int nsplit, float* ws, void* stream) {
     dvd_conv_desc d = {};
@@ -290,18 +299,32 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
                                                                        (T*)dg, 3 * h, M, h));
         ns_pending = 0;
         int ns = 0, rc;
-        if (hprev) {
-            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, h, ns_o, d->ws,
-                            stream);
+        GruEpi g = {};
+        g.h = h; g.ldg = 3 * h; g.r = const_cast<char*>(r); g.hprev = hprev; g.h32n = d->carry; g.o = dg;
+        if (hprev && ns_o == 1) {            // d(h*r) conv applies the reset-gate step in its epilogue
+            g.mode = 3;
+            rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, h, g, stream);
             if (rc) return rc;
-            ns = ns_o;
+        } else {
+            if (hprev) {
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, h, ns_o, d->ws,
+                                stream);
+                if (rc) return rc;
+                ns = ns_o;
+            }
+            BY_DTYPE(d->dtype, gru_bwd_r_kernel<T><<<grid, 256, 0, S_>>>(d->carry, d->ws, ns, (const T*)r, (const T*)hprev,
+                                                                         (T*)dg, 3 * h, M, h));
         }
-        BY_DTYPE(d->dtype, gru_bwd_r_kernel<T><<<grid, 256, 0, S_>>>(d->carry, d->ws, ns, (const T*)r, (const T*)hprev,
-                                                                     (T*)dg, 3 * h, M, h));
         if (hprev) {
-            rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, h, ns_ur, d->ws, stream);
-            if (rc) return rc;
-            ns_pending = ns_ur;
+            if (ns_ur == 1) {                // [u|r] backward-data conv adds straight into the carry
+                g.mode = 4;
+                rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, h, g, stream);
+                if (rc) return rc;
+            } else {
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, h, ns_ur, d->ws, stream);
+                if (rc) return rc;
+                ns_pending = ns_ur;
+            }
         }
     }
     if (d->dh0) gru_dh0_kernel<<<cdiv(M * h, 256), 256, 0, S_>>>(d->carry, d->ws, ns_pending, d->dh0, M, h);

@@ -92,14 +92,23 @@ __global__ void linear_fwd_kernel(const float* in, const float* W, const float* 
     a = wave_sum(a);
     if (lane == 0) out[o] = a + (bias ? bias[j] : 0.f);
 }
-// din[b][k] (+)= sum_j dout[b][j] W[j][k]
-__global__ void linear_bwd_in_kernel(const float* dout, const float* W, float* din, int B, int K, int J, int accumulate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)B * K) return;
-    const int b = (int)(i / K), k = (int)(i - (long long)b * K);
+// din[b][k] (+)= sum_j dout[b][j] W[j][k].  Block = 64 columns k x 4 j-lanes of one row b: the J loop (up to 4096
+// for the generator's first Linear) is split four ways and folded through LDS, grid (B, K/64).
+__global__ __launch_bounds__(256) void linear_bwd_in_kernel(const float* dout, const float* W, float* din, int B, int K,
+                                                            int J, int accumulate) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.x, kx = threadIdx.x & 63, jl = threadIdx.x >> 6;
+    const int k = blockIdx.y * 64 + kx;
     float a = 0.f;
-    for (int j = 0; j < J; ++j) a += dout[(size_t)b * J + j] * W[(size_t)j * K + k];
-    din[i] = accumulate ? din[i] + a : a;
+    if (k < K)
+        for (int j = jl; j < J; j += 4) a += dout[(size_t)b * J + j] * W[(size_t)j * K + k];
+    red[jl][kx] = a;
+    __syncthreads();
+    if (jl == 0 && k < K) {
+        a = (red[0][kx] + red[1][kx]) + (red[2][kx] + red[3][kx]);
+        const size_t i = (size_t)b * K + k;
+        din[i] = accumulate ? din[i] + a : a;
+    }
 }
 // dW[j][k] += sum_b dout[b][j] in[b][k];  dbias[j] += sum_b dout[b][j]
 __global__ void linear_bwd_w_kernel(const float* dout, const float* in, float* dW, float* dbias, int B, int K, int J) {
@@ -267,7 +276,7 @@ extern "C" int dvd_linear_forward(const float* in, const float* W, const float* 
 extern "C" int dvd_linear_backward(const float* dout, const float* in, const float* W, float* din, int din_accumulate,
                                    float* dW, float* dbias, int B, int K, int J, void* stream) {
     if (!dout || !in || !W || B <= 0 || K <= 0 || J <= 0) return DVD_E_ARG;
-    if (din) linear_bwd_in_kernel<<<cdiv((long long)B * K, 256), 256, 0, S_>>>(dout, W, din, B, K, J, din_accumulate);
+    if (din) linear_bwd_in_kernel<<<dim3((unsigned)B, cdiv(K, 64)), 256, 0, S_>>>(dout, W, din, B, K, J, din_accumulate);
     if (dW) linear_bwd_w_kernel<<<cdiv((long long)J * K, 256), 256, 0, S_>>>(dout, in, dW, dbias, B, K, J);
     return launch_status();
 }

@@ -246,7 +246,7 @@ def test_temporal_discriminator(golden, dtype):
 def test_convgru_large_rows_uses_fused_gate_epilogue(dtype):
     """With >= 256 output tiles the recurrent convs run without split-K and apply the gate math in
     their epilogue (csrc/conv_igemm.hip conv_store8, GruEpi).  The small golden fixtures never reach
-    that path, so it is checked here against the CPU oracle: 3 steps, B=16, 64x64, hidden 64, k=3."""
+    that path, so it is checked here against the CPU oracle: 3 steps, B=16, 64x64, hidden 64, k=3, forward and BPTT."""
     import ctypes as C
     from oracle import dvdgan_cpu as O
     from dvd_gan_amd import lib as L
@@ -258,18 +258,27 @@ def test_convgru_large_rows_uses_fused_gate_epilogue(dtype):
     for p in cell.parameters():
         if p.dim() == 1:
             p.data.normal_(0, 0.1)
-    sd = O.make_state({kk: v.detach().clone() for kk, v in cell.state_dict().items()}, requires_grad=False)
+    sd = O.make_state({kk: v.detach().clone() for kk, v in cell.state_dict().items()}, requires_grad=True)
     xs = torch.randn(T, B, cin, S, S)
+    gy = torch.randn(T, B, hid, S, S)
+    xr = xs.clone().requires_grad_(True)
     h, want = None, []
-    with torch.no_grad():
-        for i in range(T):
-            h = O.convgru_cell(sd, "", xs[i], h)
-            want.append(h)
+    for i in range(T):
+        h = O.convgru_cell(sd, "", xr[i], h)
+        want.append(h)
     want = torch.stack(want)
+    (want * gy).sum().backward()
     cell = cell.to(DEV)
-    with torch.no_grad():
-        got = ncl(cell.run(cl(xs.reshape(T * B, cin, S, S).to(DEV), dtype), T, False), hid).view(T, B, hid, S, S)
-    assert rel(got, want) < (1e-5 if dtype == torch.float32 else 1e-2)
+    xg = xs.reshape(T * B, cin, S, S).to(DEV).requires_grad_(True)
+    got = ncl(cell.run(cl(xg, dtype), T, False), hid).view(T, B, hid, S, S)
+    assert rel(got, want.detach()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # BPTT: with one output tile per workgroup the backward-data convs fold their result into the carry /
+    # gate gradients in the epilogue as well (GruEpi modes 3 and 4)
+    (got * gy.to(DEV)).sum().backward()
+    gt = 2e-5 if dtype == torch.float32 else 3e-2
+    assert rel(xg.grad.view(T, B, cin, S, S), xr.grad) < gt
+    for name, prm in cell.named_parameters():
+        assert rel(prm.grad, sd[name].grad) < gt, name
 
 
 # ------------------------------------------------------------------ BASELINE configs[3] frame size (128 x 128)
