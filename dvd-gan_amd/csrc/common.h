@@ -84,7 +84,8 @@ template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return 
 
 // Internal (not part of the public ABI): ConvGRU gate math fused into the convolution epilogue, used
 // by gru.hip when the recurrent conv needs no split-K.  mode 1: [u|r] conv, mode 2: out-gate conv (forward);
-// mode 3: d(h*r) conv of the backward pass (r, hprev, h32n = fp32 carry, o = dg base), mode 4: carry += conv.
+// mode 3: d(h*r) conv of the backward pass (r, hprev, h32n = fp32 carry, o = dg base), mode 4: carry += conv,
+// mode 5: mode 4 + first half of the next BPTT step (gx = dh_out, u_in = u, hr = o-gate, hprev, o = dg of that step).
 struct GruEpi {
     int mode, h, ldg;
     const void* gx; const void* hprev; const float* h32p; const void* u_in;

@@ -206,6 +206,31 @@ __device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, in
         store8<T>(reinterpret_cast<T*>(p.g.o) + (size_t)row * p.g.ldg + h + col, v);
         return;
     }
+    if (p.g.mode == 5) {            // BPTT: mode 4 followed by the first half of the NEXT step to process (gru_bwd_out):
+        const int h = p.g.h;        // dh = carry + acc + dh_out;  d(pre_o), d(pre_u) of that step;  carry = dh (1 - u)
+        const size_t o = (size_t)row * h + col;
+        float dh[8], t8[8], uu[8], oo[8], hp[8], dpu[8];
+        load8<float>(p.g.h32n + o, dh);
+        if (p.g.gx) {
+            load8<T>(reinterpret_cast<const T*>(p.g.gx) + o, t8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dh[k] += t8[k];
+        }
+        load8<T>(reinterpret_cast<const T*>(p.g.u_in) + o, uu);
+        load8<T>(reinterpret_cast<const T*>(p.g.hr) + o, oo);
+        if (p.g.hprev) load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = dh[k] + v[k], hpk = p.g.hprev ? hp[k] : 0.f;
+            v[k] = d * uu[k] * (1.f - oo[k] * oo[k]);                 // d(pre_o)
+            dpu[k] = d * (oo[k] - hpk) * uu[k] * (1.f - uu[k]);
+            dh[k] = d * (1.f - uu[k]);
+        }
+        store8<float>(p.g.h32n + o, dh);
+        store8<T>(reinterpret_cast<T*>(p.g.o) + (size_t)row * p.g.ldg + col, dpu);
+        store8<T>(reinterpret_cast<T*>(p.g.o) + (size_t)row * p.g.ldg + 2 * h + col, v);
+        return;
+    }
     if (p.g.mode == 4) {            // BPTT: carry += acc  (dh contribution of the [u|r] backward-data conv)
         const size_t o = (size_t)row * p.g.h + col;
         float cy[8];

@@ -288,16 +288,19 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
     hipError_t e = hipMemsetAsync(d->carry, 0, (size_t)M * h * sizeof(float), S_);
     if (e != hipSuccess) return DVD_E_LAUNCH;
     int ns_pending = 0;      // slabs of the ur backward-data conv of step t+1 waiting in ws
+    bool out_done = false;   // first half of this step already applied by the previous step's conv epilogue (mode 5)
     for (int t = d->T - 1; t >= 0; --t) {
         const char* hprev = t > 0 ? (const char*)d->h_all + (t - 1) * step : (const char*)d->h0;
         const char* u = (const char*)d->u_all + t * step; const char* r = (const char*)d->r_all + t * step;
         const char* o = (const char*)d->o_all + t * step;
         const char* dho = d->dh_out ? (const char*)d->dh_out + t * step : nullptr;
         char* dg = (char*)d->dg + (size_t)t * M * 3 * h * esz;
-        BY_DTYPE(d->dtype, gru_bwd_out_kernel<T><<<grid, 256, 0, S_>>>((const T*)dho, d->carry, d->ws, ns_pending,
-                                                                       (const T*)u, (const T*)o, (const T*)hprev,
-                                                                       (T*)dg, 3 * h, M, h));
+        if (!out_done)
+            BY_DTYPE(d->dtype, gru_bwd_out_kernel<T><<<grid, 256, 0, S_>>>((const T*)dho, d->carry, d->ws, ns_pending,
+                                                                           (const T*)u, (const T*)o, (const T*)hprev,
+                                                                           (T*)dg, 3 * h, M, h));
         ns_pending = 0;
+        out_done = false;
         int ns = 0, rc;
         GruEpi g = {};
         g.h = h; g.ldg = 3 * h; g.r = const_cast<char*>(r); g.hprev = hprev; g.h32n = d->carry; g.o = dg;
@@ -316,8 +319,18 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
                                                                          (T*)dg, 3 * h, M, h));
         }
         if (hprev) {
-            if (ns_ur == 1) {                // [u|r] backward-data conv adds straight into the carry
-                g.mode = 4;
+            if (ns_ur == 1) {                // [u|r] backward-data conv adds straight into the carry and goes on with
+                g.mode = 4;                  // the first half of step t-1 (mode 5) unless this is step 0 with an h0
+                if (t > 0) {
+                    const size_t tp = (size_t)(t - 1);
+                    g.mode = 5;
+                    g.gx = d->dh_out ? (const char*)d->dh_out + tp * step : nullptr;
+                    g.u_in = (const char*)d->u_all + tp * step;
+                    g.hr = const_cast<char*>((const char*)d->o_all + tp * step);
+                    g.hprev = t - 1 > 0 ? (const char*)d->h_all + (tp - 1) * step : (const char*)d->h0;
+                    g.o = (char*)d->dg + tp * M * 3 * h * esz;
+                    out_done = true;
+                }
                 rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, h, g, stream);
                 if (rc) return rc;
             } else {
