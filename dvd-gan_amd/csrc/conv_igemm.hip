@@ -1437,7 +1437,8 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
-    const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= 512;   // >= 2 workgroups per CU
+    static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;
+    const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= big_thr;   // >= 2 workgroups per CU
     dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
