@@ -481,14 +481,16 @@ template <bool UP2> struct HaloGeo {
     static __device__ __forceinline__ int sw(int hy, int hx) { return ((hx >> 2) + SWA * hy) & 3; }
 };
 
-template <typename T, int TM, int WN, bool RELU, bool UP2>   // waves: 2 (M) x WN (N); block tile (TM*64 pixels) x (WN*64)
-__global__ __launch_bounds__(128 * WN) void conv_halo_kernel(ConvK p) {
+// waves: WMV (M) x WN (N); block tile (WMV*TM*32 pixels) x (WN*64).  WMV = 4, TM = 2, WN = 1 is the 256 x 64 tile of
+// the thin convs (Cout <= 64: a 128-wide N tile would multiply zeros half of the time)
+template <typename T, int TM, int WN, bool RELU, bool UP2, int WMV = 2>
+__global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
     using G = HaloGeo<UP2>;
     constexpr int PITCH = G::PITCH;
     constexpr int E16 = ElemTraits<T>::kPer16B;
     constexpr int BK = 4 * E16;
-    constexpr int BMt = TM * 64, BNt = WN * 64;
-    constexpr int NWAVE = 2 * WN;
+    constexpr int BMt = WMV * TM * 32, BNt = WN * 64;
+    constexpr int NWAVE = WMV * WN;
     constexpr int PH = BMt / 16;                              // patch: PH rows x 16 columns of one frame
     constexpr int HG = UP2 ? ((PH / 2 + 3) * PITCH + 15) / 16 // 16-row DMA groups of the largest footprint
                            : ((PH + 4) * PITCH + 15) / 16;    //   (5 x 5 taps)
@@ -1434,8 +1436,9 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     static const int use_halo = getenv("DVD_CONV_HALO") ? atoi(getenv("DVD_CONV_HALO")) : 1;
     const bool halo = use_halo && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->W >= 16 && d->H >= 16 &&
                       p.nsplit <= p.kchunks * d->kt;
+    const bool thin = halo && d->dtype == DVD_BF16 && d->Cout <= 64 && cdiv(M, 256) * (long long)p.nsplit >= 512;
     const bool wide = !halo && d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
-    p.tilesN = wide ? (d->Cout + 255) / 256 : (d->Cout + BN - 1) / BN;
+    p.tilesN = wide ? (d->Cout + 255) / 256 : thin ? 1 : (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};
     {   // extents of the two buffer descriptors (32-bit byte offsets): tensors must stay below 4 GiB
@@ -1460,7 +1463,12 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
              else conv_halo_kernel<TT, TM_, WN_, RL_, false><<<grid, 128 * WN_, 0, st>>>(p); } while (0)
 #define LAUNCH_HALO(TT, TM_, WN_)                                                                   \
         do { if (d->relu_in) LAUNCH_HALO2(TT, TM_, WN_, true); else LAUNCH_HALO2(TT, TM_, WN_, false); } while (0)
-        if (d->dtype == DVD_BF16) { if (big) LAUNCH_HALO(bf16_t, 4, 2); else LAUNCH_HALO(bf16_t, 2, 2); }
+        if (thin) {
+            if (d->relu_in) { if (d->up2) conv_halo_kernel<bf16_t, 2, 1, true, true, 4><<<grid, 256, 0, st>>>(p);
+                              else conv_halo_kernel<bf16_t, 2, 1, true, false, 4><<<grid, 256, 0, st>>>(p); }
+            else            { if (d->up2) conv_halo_kernel<bf16_t, 2, 1, false, true, 4><<<grid, 256, 0, st>>>(p);
+                              else conv_halo_kernel<bf16_t, 2, 1, false, false, 4><<<grid, 256, 0, st>>>(p); }
+        } else if (d->dtype == DVD_BF16) { if (big) LAUNCH_HALO(bf16_t, 4, 2); else LAUNCH_HALO(bf16_t, 2, 2); }
         else if (d->dtype == DVD_F32) { if (big) LAUNCH_HALO(float, 4, 2); else LAUNCH_HALO(float, 2, 2); }
         else return DVD_E_ARG;
 #undef LAUNCH_HALO

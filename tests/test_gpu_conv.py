@@ -48,7 +48,9 @@ CASES = [
     (2, 24, 40, (16, 16), (3, 3), True, True),       # nearest x2 folded into the footprint, ReLU on fragments
     (2, 16, 24, (16, 64), (3, 3), False, False),     # H != W
     (1, 8, 16, (4, 16, 16), (3, 3, 3), False, False),  # 3-D: footprint from frame t+dt
-    (32, 16, 40, (64, 64), (5, 5), False, True),     # 512 tiles of 256 x 128: the 16 x 16 patch variant
+    (32, 16, 40, (64, 64), (5, 5), False, True),     # 512 tiles, Cout <= 64: the 256 x 64 thin-output variant
+    (8, 24, 40, (64, 64), (3, 3), True, False),      # thin-output variant with the x2 upsample folded in
+    (32, 16, 72, (64, 64), (3, 3), False, True),     # 512 tiles of 256 x 128: the 16 x 16 patch variant
     (16, 40, 264, (64, 64), (5, 5), False, False),   # 8-wave 256 x 256 variant, 5x5, ragged N
     # filter-row weight-gradient kernel (Cout >= 96, Cin >= 48, W >= 16)
     (3, 72, 136, (16, 16), (5, 5), False, False),    # W = 16: a 32-pixel step is two lines; 128-channel tile, ragged
@@ -121,7 +123,8 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     assert rel(dw.cpu(), wr.grad) < (5e-6 if exact else 6e-3)
     dw2 = torch.zeros_like(dw)
     K.conv_wgrad(xc, gyc, dw2, ks, Cout, Cin, up2=up2, relu_in=relu_in, msplit=1)
-    assert rel(dw2.cpu(), wq_.grad) < 5e-6
+    # one slice = one fp32 accumulator chain over all M rows: rounding grows with the chain length (131072 rows: 6.5e-6)
+    assert rel(dw2.cpu(), wq_.grad) < 1e-5
 
 
 def test_bad_shapes_raise():
