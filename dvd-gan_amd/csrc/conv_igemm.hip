@@ -1544,6 +1544,15 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
         const long long cap = M / minrows > 0 ? M / minrows : 1;
         if (msplit > cap) msplit = cap;
+        // whole rounds: the workgroups run `conc` at a time (register / LDS limited); a grid a few workgroups over a
+        // multiple of that pays a full extra round (20 x 103 = 2060 workgroups = 8.05 rounds of 256 -> 9 rounds)
+        static const int quant = getenv("DVD_WG_QUANT") ? atoi(getenv("DVD_WG_QUANT")) : 1;
+        const long long conc = 256ll * ((mode == 1 && ta == 4) ? 1 : 2);
+        if (quant && base * msplit > conc) {
+            const long long rounds = (base * msplit + conc / 2) / conc;           // nearest
+            long long ms2 = rounds * conc / base;
+            if (ms2 >= 1 && ms2 <= cap) msplit = ms2;
+        }
     }
     long long rows = (M + msplit - 1) / msplit;
     {   // a workgroup's row slice is addressed with 32-bit byte offsets
