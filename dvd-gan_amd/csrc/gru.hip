@@ -205,12 +205,13 @@ int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int
     } while (0)
 
 // Split-K factor that brings a conv with few output tiles up to ~two workgroups per CU (measured on the
-// full step: target 128 -> 948 ms, 256 -> 922, 384 -> 917, 512 -> 913).
+// full step: target 128 -> 948 ms, 256 -> 922, 384 -> 917, 512 -> 913; re-swept with the halo kernels, where a split
+// shape gets the 256 x 128 tile at two workgroups per CU: 512 -> 642 ms, 768 -> 634, 1024 -> 626, 1536 -> 661).
 extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps) {
     const int bk = dtype == DVD_BF16 ? 32 : 16;
     const long long nk = (long long)ntaps * ((C + bk - 1) / bk);
     const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    static const long long target = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 512;
+    static const long long target = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 1024;
     long long ns = (target + tiles - 1) / tiles;
     if (ns > 16) ns = 16;
     if (ns > nk) ns = nk;

@@ -246,12 +246,12 @@ def test_temporal_discriminator(golden, dtype):
 def test_convgru_large_rows_uses_fused_gate_epilogue(dtype):
     """With >= 256 output tiles the recurrent convs run without split-K and apply the gate math in
     their epilogue (csrc/conv_igemm.hip conv_store8, GruEpi).  The small golden fixtures never reach
-    that path, so it is checked here against the CPU oracle: 3 steps, B=16, 64x64, hidden 64, k=3, forward and BPTT."""
+    that path, so it is checked here against the CPU oracle: 3 steps, B=32, 64x64, hidden 64, k=3, forward and BPTT."""
     import ctypes as C
     from oracle import dvdgan_cpu as O
     from dvd_gan_amd import lib as L
     from dvd_gan_amd.gen_net import ConvGRUCell
-    T, B, S, cin, hid, k = 3, 16, 64, 8, 64, 3
+    T, B, S, cin, hid, k = 3, 32, 64, 8, 64, 3
     assert L.lib().dvd_conv_pick_nsplit(L.BF16, C.c_longlong(B * S * S), 2 * hid, hid, k * k) == 1
     torch.manual_seed(11)
     cell = ConvGRUCell(cin, hid, k)
