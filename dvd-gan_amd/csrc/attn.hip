@@ -4,7 +4,10 @@
 // `qkv`).  N = H*W tokens per frame (256 / 64 at the 64x64 configuration), dq = C/8.
 // fp32 arithmetic on the vector pipe: the whole attention is < 0.2 % of the step's FLOPs, so the
 // kernels are organised for exactness and simple, coalesced access rather than MFMA.
-// A ([F][N][N] fp32) and out are kept for the backward pass.
+// A ([F][N][Nk] fp32) and out are kept for the backward pass.
+// The kernels take the keys / values from a separate row set (`kv`, Nk rows per frame): Nk = N and kv = qkv for the
+// discriminators' 2-D block; for the spatio-temporal block of Module/Attention.py:114-185 the keys and values are the
+// 2x2x2 max-pooled projections (Nk = N/8) and the query axis runs over all T*H*W tokens of a clip.
 #include "common.h"
 
 namespace {
@@ -24,19 +27,20 @@ __device__ float blk_sum(float v, float* sh) {
 }
 
 template <typename T, int QB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* x,
-                                                       int ldx, int C, const float* gamma, T* y, T* att_out,
-                                                       float* A, int N) {
-    extern __shared__ float S[];                   // [QB][N]
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, int dq, const T* kv, int ldk, int koff,
+                                                       int voff, const T* x, int ldx, int C, const float* gamma, T* y,
+                                                       T* att_out, float* A, int N, int Nk) {
+    extern __shared__ float S[];                   // [QB][Nk]
     const int f = blockIdx.y, i0 = blockIdx.x * QB, tid = threadIdx.x;
     const T* qf = qkv + (size_t)f * N * ldq;
+    const T* kf = kv + (size_t)f * Nk * ldk;
     // ---- scores ----
-    for (int idx = tid; idx < QB * N; idx += 256) {
-        const int i = idx / N, j = idx - i * N;
+    for (int idx = tid; idx < QB * Nk; idx += 256) {
+        const int i = idx / Nk, j = idx - i * Nk;
         float s = 0.f;
         if (i0 + i < N) {
             const T* q = qf + (size_t)(i0 + i) * ldq;
-            const T* k = qf + (size_t)j * ldq + koff;
+            const T* k = kf + (size_t)j * ldk + koff;
             for (int d = 0; d < dq; ++d) s += ldf(q + d) * ldf(k + d);
         }
         S[idx] = s;
@@ -46,16 +50,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, in
     const int wave = tid >> 6, lane = tid & 63;
     for (int i = wave; i < QB; i += 4) {
         float m = -INFINITY;
-        for (int j = lane; j < N; j += 64) m = fmaxf(m, S[i * N + j]);
+        for (int j = lane; j < Nk; j += 64) m = fmaxf(m, S[i * Nk + j]);
         m = wave_max(m);
         float sum = 0.f;
-        for (int j = lane; j < N; j += 64) { const float e = expf(S[i * N + j] - m); S[i * N + j] = e; sum += e; }
+        for (int j = lane; j < Nk; j += 64) { const float e = expf(S[i * Nk + j] - m); S[i * Nk + j] = e; sum += e; }
         sum = wave_sum(sum);
         const float inv = 1.f / sum;
-        for (int j = lane; j < N; j += 64) {
-            const float a = S[i * N + j] * inv;
-            S[i * N + j] = a;
-            if (A && i0 + i < N) A[((size_t)f * N + i0 + i) * N + j] = a;
+        for (int j = lane; j < Nk; j += 64) {
+            const float a = S[i * Nk + j] * inv;
+            S[i * Nk + j] = a;
+            if (A && i0 + i < N) A[((size_t)f * N + i0 + i) * Nk + j] = a;
         }
     }
     __syncthreads();
@@ -64,10 +68,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, in
     for (int idx = tid; idx < (QB / 4) * C; idx += 256) {
         const int ib = (idx / C) * 4, c = idx % C;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < N; ++j) {
-            const float vv = ldf(qf + (size_t)j * ldq + voff + c);
+        for (int j = 0; j < Nk; ++j) {
+            const float vv = ldf(kf + (size_t)j * ldk + voff + c);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += S[(ib + r) * N + j] * vv;
+            for (int r = 0; r < 4; ++r) acc[r] += S[(ib + r) * Nk + j] * vv;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -82,13 +86,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, in
 
 // Backward, row pass: dA, dS (written over `dS` [F][N][N]), dq, dgamma.
 template <typename T, int QB>
-__global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* dy,
+__global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* kv, int ldk, int dq, int koff, int voff, const T* dy,
                                                             int ldx, int C, const float* gamma, const T* att_out,
-                                                            const float* A, float* dS, T* dqkv, float* dgamma, int N) {
-    extern __shared__ float S[];                   // [QB][N] dA -> dS
+                                                            const float* A, float* dS, T* dqo, int ldq, float* dgamma,
+                                                            int N, int Nk) {
+    extern __shared__ float S[];                   // [QB][Nk] dA -> dS
     __shared__ float sh[4];
     const int f = blockIdx.y, i0 = blockIdx.x * QB, tid = threadIdx.x;
-    const T* qf = qkv + (size_t)f * N * ldq;
+    const T* kf = kv + (size_t)f * Nk * ldk;
     const float g = *gamma;
     // dgamma partial: sum dy * att_out over this block's rows
     float dgp = 0.f;
@@ -103,17 +108,17 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ld
     if (tid == 0 && dgamma) atomicAdd(dgamma, dgp);
     // dA[i][j] = gamma * sum_c dy[i][c] v[j][c]: the block's QB rows of dy are staged in LDS as
     // floats; thread j streams its v row with 16-byte loads and keeps QB accumulators.
-    float* dyl = S + QB * N;                        // [QB][C]
+    float* dyl = S + QB * Nk;                       // [QB][C]
     for (int idx = tid; idx < QB * C; idx += 256) {
         const int i = idx / C, c = idx - i * C;
         dyl[idx] = (i0 + i < N) ? ldf(dy + ((size_t)f * N + i0 + i) * ldx + c) : 0.f;
     }
     __syncthreads();
-    for (int j = tid; j < N; j += 256) {
+    for (int j = tid; j < Nk; j += 256) {
         float acc[QB];
 #pragma unroll
         for (int i = 0; i < QB; ++i) acc[i] = 0.f;
-        const T* v = qf + (size_t)j * ldq + voff;
+        const T* v = kf + (size_t)j * ldk + voff;
         for (int c = 0; c < C; c += 8) {
             float vv[8];
             load8<T>(v + c, vv);                    // C is a multiple of 8, voff too
@@ -125,21 +130,21 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ld
             }
         }
 #pragma unroll
-        for (int i = 0; i < QB; ++i) S[i * N + j] = acc[i] * g;
+        for (int i = 0; i < QB; ++i) S[i * Nk + j] = acc[i] * g;
     }
     __syncthreads();
     // dS = A * (dA - sum_j A dA)
     const int wave = tid >> 6, lane = tid & 63;
     for (int i = wave; i < QB; i += 4) {
         if (i0 + i >= N) continue;
-        const float* a = A + ((size_t)f * N + i0 + i) * N;
+        const float* a = A + ((size_t)f * N + i0 + i) * Nk;
         float dot = 0.f;
-        for (int j = lane; j < N; j += 64) dot += a[j] * S[i * N + j];
+        for (int j = lane; j < Nk; j += 64) dot += a[j] * S[i * Nk + j];
         dot = wave_sum(dot);
-        for (int j = lane; j < N; j += 64) {
-            const float v = a[j] * (S[i * N + j] - dot);
-            S[i * N + j] = v;
-            dS[((size_t)f * N + i0 + i) * N + j] = v;
+        for (int j = lane; j < Nk; j += 64) {
+            const float v = a[j] * (S[i * Nk + j] - dot);
+            S[i * Nk + j] = v;
+            dS[((size_t)f * N + i0 + i) * Nk + j] = v;
         }
     }
     __syncthreads();
@@ -148,8 +153,8 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ld
         const int i = idx / dq, d = idx - i * dq;
         if (i0 + i >= N) continue;
         float s = 0.f;
-        for (int j = 0; j < N; ++j) s += S[i * N + j] * ldf(qf + (size_t)j * ldq + koff + d);
-        stf(dqkv + ((size_t)f * N + i0 + i) * ldq + d, s);
+        for (int j = 0; j < Nk; ++j) s += S[i * Nk + j] * ldf(kf + (size_t)j * ldk + koff + d);
+        stf(dqo + ((size_t)f * N + i0 + i) * ldq + d, s);
     }
 }
 
@@ -157,14 +162,14 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* qkv, int ld
 template <typename T, int QB>
 __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const T* qkv, int ldq, int dq, int koff, int voff, const T* dy,
                                                             int ldx, int C, const float* gamma, const float* A,
-                                                            const float* dS, T* dqkv, int N) {
+                                                            const float* dS, T* dkv, int ldk, int N, int Nk) {
     extern __shared__ float S[];                   // [N][QB] slice of A, then of dS (column block j0..j0+QB)
     const int f = blockIdx.y, j0 = blockIdx.x * QB, tid = threadIdx.x;
     const T* qf = qkv + (size_t)f * N * ldq;
     const float g = *gamma;
     for (int idx = tid; idx < N * QB; idx += 256) {
         const int i = idx / QB, jj = idx - i * QB;
-        S[idx] = (j0 + jj < N) ? A[((size_t)f * N + i) * N + j0 + jj] : 0.f;
+        S[idx] = (j0 + jj < Nk) ? A[((size_t)f * N + i) * Nk + j0 + jj] : 0.f;
     }
     __syncthreads();
     for (int idx = tid; idx < (QB / 4) * C; idx += 256) {
@@ -177,20 +182,20 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const T* qkv, int ld
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (j0 + jb + r < N) stf(dqkv + ((size_t)f * N + j0 + jb + r) * ldq + voff + c, g * acc[r]);
+            if (j0 + jb + r < Nk) stf(dkv + ((size_t)f * Nk + j0 + jb + r) * ldk + voff + c, g * acc[r]);
     }
     __syncthreads();
     for (int idx = tid; idx < N * QB; idx += 256) {
         const int i = idx / QB, jj = idx - i * QB;
-        S[idx] = (j0 + jj < N) ? dS[((size_t)f * N + i) * N + j0 + jj] : 0.f;
+        S[idx] = (j0 + jj < Nk) ? dS[((size_t)f * N + i) * Nk + j0 + jj] : 0.f;
     }
     __syncthreads();
     for (int idx = tid; idx < QB * dq; idx += 256) {
         const int jj = idx / dq, d = idx - jj * dq;
-        if (j0 + jj >= N) continue;
+        if (j0 + jj >= Nk) continue;
         float s = 0.f;
         for (int i = 0; i < N; ++i) s += S[i * QB + jj] * ldf(qf + (size_t)i * ldq + d);
-        stf(dqkv + ((size_t)f * N + j0 + jj) * ldq + koff + d, s);
+        stf(dkv + ((size_t)f * Nk + j0 + jj) * ldk + koff + d, s);
     }
 }
 
@@ -204,40 +209,67 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const T* qkv, int ld
         else return DVD_E_ARG;                                                 \
     } while (0)
 
-extern "C" int dvd_attention_forward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* x,
-                                     int ldx, int C, const float* gamma, void* y, void* att_out, float* A,
-                                     long long frames, int N, void* stream) {
-    if (!qkv || !x || !gamma || !y || frames <= 0 || N <= 0 || dq <= 0 || C <= 0) return DVD_E_ARG;
+static int attention_fwd(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff, const void* x,
+                         int ldx, int C, const float* gamma, void* y, void* att_out, float* A, long long frames, int N, int Nk,
+                         void* stream) {
+    if (!q || !kv || !x || !gamma || !y || frames <= 0 || N <= 0 || Nk <= 0 || dq <= 0 || C <= 0) return DVD_E_ARG;
     if (frames > 65535) return DVD_E_SHAPE;
-    const int qb = (size_t)16 * N * sizeof(float) <= 64 * 1024 ? 16 : 8;
-    if ((size_t)qb * N * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    const int qb = (size_t)16 * Nk * sizeof(float) <= 64 * 1024 ? 16 : 8;
+    if ((size_t)qb * Nk * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
     dim3 grid(cdiv(N, qb), (unsigned)frames);
-    const size_t sh = (size_t)qb * N * sizeof(float);
-#define ATT_FWD(QB_) BY_DTYPE(dtype, attn_fwd_kernel<T, QB_><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff, \
-                                       (const T*)x, ldx, C, gamma, (T*)y, (T*)att_out, A, N))
+    const size_t sh = (size_t)qb * Nk * sizeof(float);
+#define ATT_FWD(QB_) BY_DTYPE(dtype, attn_fwd_kernel<T, QB_><<<grid, 256, sh, S_>>>((const T*)q, ldq, dq, (const T*)kv, ldk, koff, \
+                                       voff, (const T*)x, ldx, C, gamma, (T*)y, (T*)att_out, A, N, Nk))
     if (qb == 16) ATT_FWD(16); else ATT_FWD(8);
 #undef ATT_FWD
     return launch_status();
 }
 
-extern "C" int dvd_attention_backward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* dy,
-                                      int ldx, int C, const float* gamma, const void* att_out, const float* A,
-                                      float* dS, void* dqkv, float* dgamma, long long frames, int N, void* stream) {
-    if (!qkv || !dy || !gamma || !att_out || !A || !dS || !dqkv || frames <= 0 || N <= 0) return DVD_E_ARG;
+static int attention_bwd(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff, const void* dy,
+                         int ldx, int C, const float* gamma, const void* att_out, const float* A, float* dS, void* dqo,
+                         void* dkv, float* dgamma, long long frames, int N, int Nk, void* stream) {
+    if (!q || !kv || !dy || !gamma || !att_out || !A || !dS || !dqo || !dkv || frames <= 0 || N <= 0 || Nk <= 0) return DVD_E_ARG;
     if (frames > 65535 || (C & 7)) return DVD_E_SHAPE;
-    const int qb = (size_t)16 * (N + C) * sizeof(float) <= 64 * 1024 ? 16 : 8;
-    if ((size_t)qb * (N + C) * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
-    dim3 grid(cdiv(N, qb), (unsigned)frames);
-    const size_t sh = (size_t)qb * N * sizeof(float);
-    const size_t sh_rows = sh + (size_t)qb * C * sizeof(float);
-#define ATT_BWD(QB_)                                                                                                  \
-    do {                                                                                                              \
-        BY_DTYPE(dtype, attn_bwd_rows_kernel<T, QB_><<<grid, 256, sh_rows, S_>>>((const T*)qkv, ldq, dq, koff, voff,  \
-                            (const T*)dy, ldx, C, gamma, (const T*)att_out, A, dS, (T*)dqkv, dgamma, N));             \
-        BY_DTYPE(dtype, attn_bwd_cols_kernel<T, QB_><<<grid, 256, sh, S_>>>((const T*)qkv, ldq, dq, koff, voff,       \
-                            (const T*)dy, ldx, C, gamma, A, dS, (T*)dqkv, N));                                        \
+    const int qb = ((size_t)16 * (Nk + C) * sizeof(float) <= 64 * 1024 && (size_t)16 * N * sizeof(float) <= 64 * 1024) ? 16 : 8;
+    if ((size_t)qb * (Nk + C) * sizeof(float) > 64 * 1024 || (size_t)qb * N * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    dim3 grid_r(cdiv(N, qb), (unsigned)frames), grid_c(cdiv(Nk, qb), (unsigned)frames);
+    const size_t sh_rows = (size_t)qb * (Nk + C) * sizeof(float), sh_cols = (size_t)qb * N * sizeof(float);
+#define ATT_BWD(QB_)                                                                                                    \
+    do {                                                                                                                \
+        BY_DTYPE(dtype, attn_bwd_rows_kernel<T, QB_><<<grid_r, 256, sh_rows, S_>>>((const T*)kv, ldk, dq, koff, voff,   \
+                            (const T*)dy, ldx, C, gamma, (const T*)att_out, A, dS, (T*)dqo, ldq, dgamma, N, Nk));       \
+        BY_DTYPE(dtype, attn_bwd_cols_kernel<T, QB_><<<grid_c, 256, sh_cols, S_>>>((const T*)q, ldq, dq, koff, voff,    \
+                            (const T*)dy, ldx, C, gamma, A, dS, (T*)dkv, ldk, N, Nk));                                  \
     } while (0)
     if (qb == 16) ATT_BWD(16); else ATT_BWD(8);
 #undef ATT_BWD
     return launch_status();
+}
+
+extern "C" int dvd_attention_forward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* x,
+                                     int ldx, int C, const float* gamma, void* y, void* att_out, float* A,
+                                     long long frames, int N, void* stream) {
+    return attention_fwd(dtype, qkv, ldq, dq, qkv, ldq, koff, voff, x, ldx, C, gamma, y, att_out, A, frames, N, N, stream);
+}
+
+extern "C" int dvd_attention_backward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* dy,
+                                      int ldx, int C, const float* gamma, const void* att_out, const float* A,
+                                      float* dS, void* dqkv, float* dgamma, long long frames, int N, void* stream) {
+    return attention_bwd(dtype, qkv, ldq, dq, qkv, ldq, koff, voff, dy, ldx, C, gamma, att_out, A, dS, dqkv, dqkv, dgamma,
+                         frames, N, N, stream);
+}
+
+// Queries from `q` (N rows per frame), keys / values from `kv` (Nk rows per frame, columns [koff,koff+dq) / [voff,voff+C)).
+extern "C" int dvd_attention_kv_forward(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff,
+                                        const void* x, int ldx, int C, const float* gamma, void* y, void* att_out, float* A,
+                                        long long frames, int N, int Nk, void* stream) {
+    return attention_fwd(dtype, q, ldq, dq, kv, ldk, koff, voff, x, ldx, C, gamma, y, att_out, A, frames, N, Nk, stream);
+}
+
+extern "C" int dvd_attention_kv_backward(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff,
+                                         const void* dy, int ldx, int C, const float* gamma, const void* att_out,
+                                         const float* A, float* dS, void* dq_out, void* dkv_out, float* dgamma,
+                                         long long frames, int N, int Nk, void* stream) {
+    return attention_bwd(dtype, q, ldq, dq, kv, ldk, koff, voff, dy, ldx, C, gamma, att_out, A, dS, dq_out, dkv_out, dgamma,
+                         frames, N, Nk, stream);
 }

@@ -259,6 +259,62 @@ __global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, in
     for (int k = 0; k < 8; ++k) acc[k] *= scale;
     store8<T>(y + (size_t)(i / cg) * ld + g * 8, acc);
 }
+// 2x2x2 max pooling (stride 2) of a channels-last [f][T][H][W][c] tensor: Module/Attention.py:148 (nn.MaxPool3d(2, 2)).
+template <typename T>
+__global__ void maxpool3d_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld) {
+    const int cg = ld / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout * cg) return;
+    long long r = i / cg;
+    const int g = (int)(i - r * cg);
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int to = (int)(r % To);
+    const long long f = r / To;
+    const int Ti = To * 2, Hi = Ho * 2, Wi = Wo * 2;
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+    for (int w = 0; w < 8; ++w) {
+        float v[8];
+        load8<T>(x + ((((size_t)f * Ti + to * 2 + (w >> 2)) * Hi + yo * 2 + ((w >> 1) & 1)) * Wi + xo * 2 + (w & 1)) * ld + g * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = v[k] > m[k] ? v[k] : m[k];
+    }
+    store8<T>(y + (size_t)(i / cg) * ld + g * 8, m);
+}
+// backward: the gradient of a window goes to its FIRST maximum in (t, h, w) scan order (torch's tie rule: strict >);
+// windows do not overlap, so every input element is written exactly once
+template <typename T>
+__global__ void maxpool3d_bwd_kernel(const T* x, const T* dy, T* dx, long long nout, int To, int Ho, int Wo, int ld) {
+    const int cg = ld / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout * cg) return;
+    long long r = i / cg;
+    const int g = (int)(i - r * cg);
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int to = (int)(r % To);
+    const long long f = r / To;
+    const int Ti = To * 2, Hi = Ho * 2, Wi = Wo * 2;
+    float m[8], gy[8];
+    int arg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; arg[k] = 0; }
+    for (int w = 0; w < 8; ++w) {
+        float v[8];
+        load8<T>(x + ((((size_t)f * Ti + to * 2 + (w >> 2)) * Hi + yo * 2 + ((w >> 1) & 1)) * Wi + xo * 2 + (w & 1)) * ld + g * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (v[k] > m[k]) { m[k] = v[k]; arg[k] = w; }
+    }
+    load8<T>(dy + (size_t)(i / cg) * ld + g * 8, gy);
+    for (int w = 0; w < 8; ++w) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = arg[k] == w ? gy[k] : 0.f;
+        store8<T>(dx + ((((size_t)f * Ti + to * 2 + (w >> 2)) * Hi + yo * 2 + ((w >> 1) & 1)) * Wi + xo * 2 + (w & 1)) * ld + g * 8, o);
+    }
+}
 // y[f][t][y][x][c] = scale * x[f][t/pt][y/2][x/2][c]
 template <typename T>
 __global__ void unpool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld, int pt, float scale) {
@@ -455,6 +511,23 @@ extern "C" int dvd_pool(int dtype, const void* x, void* y, long long frames, int
     if (ld & 7) return DVD_E_SHAPE;
     const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
     BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale));
+    return launch_status();
+}
+// 2x2x2 max pooling; output grid frames x To x Ho x Wo (input 2To x 2Ho x 2Wo)
+extern "C" int dvd_maxpool3d(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, void* stream) {
+    if (!x || !y || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0) return DVD_E_ARG;
+    if (ld & 7) return DVD_E_SHAPE;
+    const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
+    BY_DTYPE(dtype, maxpool3d_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld));
+    return launch_status();
+}
+extern "C" int dvd_maxpool3d_backward(int dtype, const void* x, const void* dy, void* dx, long long frames, int To, int Ho,
+                                      int Wo, int ld, void* stream) {
+    if (!x || !dy || !dx || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0) return DVD_E_ARG;
+    if (ld & 7) return DVD_E_SHAPE;
+    const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
+    BY_DTYPE(dtype, maxpool3d_bwd_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (const T*)dy, (T*)dx, nout, To, Ho,
+                                                                          Wo, ld));
     return launch_status();
 }
 // y[t][y][x] = scale * x[t/pt][y/2][x/2]; output grid frames x To x Ho x Wo

@@ -284,6 +284,67 @@ class SelfAttention2d(Function):
         return dy, dqkv, dgamma, None, None
 
 
+class MaxPool3d(Function):
+    """nn.MaxPool3d(2, 2) on a channels-last [F, T, H, W, C] tensor (Attention.py:148)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        F_, T, H, W, ld = x.shape
+        y = torch.empty(F_, T // 2, H // 2, W // 2, ld, dtype=x.dtype, device=x.device)
+        L.check(L.lib().dvd_maxpool3d(L.dt(x), L.ptr(x), L.ptr(y), C.c_longlong(F_), T // 2, H // 2, W // 2, ld, L.stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        F_, T, H, W, ld = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.lib().dvd_maxpool3d_backward(L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), C.c_longlong(F_), T // 2, H // 2,
+                                               W // 2, ld, L.stream()))
+        return dx
+
+
+class SelfAttentionKV(Function):
+    """y = gamma * softmax(q k^T) v + x with the keys / values on their own (pooled) token set
+    (Attention.py:160-179).  q: columns [0, dq) of `qkv` (N tokens per clip); k, v: columns [koff, koff+dq) and
+    [voff, voff+C) of `kv` (Nk tokens per clip)."""
+
+    @staticmethod
+    def forward(ctx, x, qkv, kv, gamma, dq, C_real):
+        F_ = x.shape[0]
+        N = x.numel() // (F_ * x.shape[-1])
+        Nk = kv.numel() // (F_ * kv.shape[-1])
+        koff = K.pad8(dq)
+        voff = 2 * koff
+        y = torch.zeros_like(x) if x.shape[-1] != C_real else torch.empty_like(x)
+        att = torch.zeros_like(x)
+        A = torch.empty(F_, N, Nk, dtype=torch.float32, device=x.device)
+        L.check(L.lib().dvd_attention_kv_forward(L.dt(x), L.ptr(qkv), qkv.shape[-1], dq, L.ptr(kv), kv.shape[-1], koff, voff,
+                                                 L.ptr(x), x.shape[-1], C_real, L.ptr(gamma), L.ptr(y), L.ptr(att), L.ptr(A),
+                                                 C.c_longlong(F_), N, Nk, L.stream()))
+        ctx.save_for_backward(qkv, kv, gamma, att, A)
+        ctx.meta = (dq, C_real, koff, voff, N, Nk)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qkv, kv, gamma, att, A = ctx.saved_tensors
+        dq, C_real, koff, voff, N, Nk = ctx.meta
+        dy = dy.contiguous()
+        F_ = dy.shape[0]
+        dqkv = torch.zeros_like(qkv)          # only the q columns are written here
+        dkv = torch.zeros_like(kv)            # k and v columns
+        dS = torch.empty_like(A)
+        dgamma = torch.zeros(1, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().dvd_attention_kv_backward(L.dt(dy), L.ptr(qkv), qkv.shape[-1], dq, L.ptr(kv), kv.shape[-1], koff,
+                                                  voff, L.ptr(dy), dy.shape[-1], C_real, L.ptr(gamma), L.ptr(att), L.ptr(A),
+                                                  L.ptr(dS), L.ptr(dqkv), L.ptr(dkv), L.ptr(dgamma), C.c_longlong(F_), N, Nk,
+                                                  L.stream()))
+        return dy, dqkv, dkv, dgamma, None, None
+
+
 class ProjectionHead(Function):
     """out[f] = b + sum_c h[f][c] * (w_lin[c]/s_l + embed[cls[f]][c]/s_e),  h = sum_p relu(feat)
     Discriminators.py:264-291 / 421-447 (both SN wrappers have their own sigma)."""

@@ -230,6 +230,23 @@ int dvd_attention_backward(int dtype, const void* qkv, int ldq, int dq, int koff
                            int C, const float* gamma, const void* att_out, const float* A, float* dS, void* dqkv,
                            float* dgamma, long long frames, int N, void* stream);
 
+/* Spatio-temporal self attention (Module/Attention.py:114-185, SelfAttention over the T*H*W token axis; defined by the
+ * reference, not invoked by its Generator): queries from `q` (N rows per clip), keys / values from `kv` -- the
+ * 2x2x2 max-pooled projections, Nk = N/8 rows per clip, columns [koff,koff+dq) / [voff,voff+C); A is [frames][N][Nk].
+ * softmax(q k^T) (:166-167), V A^T (:172), gamma*out + x (:179). */
+int dvd_attention_kv_forward(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff,
+                             const void* x, int ldx, int C, const float* gamma, void* y, void* att_out, float* A,
+                             long long frames, int N, int Nk, void* stream);
+int dvd_attention_kv_backward(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff,
+                              const void* dy, int ldx, int C, const float* gamma, const void* att_out, const float* A,
+                              float* dS, void* dq_out, void* dkv_out, float* dgamma, long long frames, int N, int Nk,
+                              void* stream);
+/* nn.MaxPool3d(kernel_size=2, stride=2) of Module/Attention.py:148,164,170 on a channels-last [frames][2To][2Ho][2Wo][ld]
+ * tensor and its backward (gradient to the first maximum of each window) */
+int dvd_maxpool3d(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, void* stream);
+int dvd_maxpool3d_backward(int dtype, const void* x, const void* dy, void* dx, long long frames, int To, int Ho, int Wo,
+                           int ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,6 +151,49 @@ def test_attention(golden, tag, C, dtype):
     check_param_grads(at, sub(g, "grad"), gt)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_3d_golden(golden, dtype):
+    """Module/Attention.py:114-185 (T*W*H tokens, 2x2x2 max-pooled keys / values) against the reference fixture."""
+    from dvd_gan_amd.attention3d import SelfAttention
+    g = sub(golden("f5_attention"), "attn3d")
+    at = load(SelfAttention(8, compute_dtype=dtype), sub(g, "sd0"))
+    x = t(g["in.x"], True)
+    y = at(x)
+    ft, gt = TOL[dtype]
+    assert rel(y, g["out.y"]) < ft
+    y.backward(t(g["in.gy"]))
+    assert rel(x.grad, g["grad.x"]) < gt
+    check_param_grads(at, sub(g, "grad"), gt)
+
+
+def test_attention_3d_768_tokens_vs_oracle():
+    """The shape the reference's generator would use it at ([B, 256, 48, 4, 4]-like: N = 768 tokens, 96 keys), reduced to
+    32 channels, against the CPU oracle in exact mode."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.attention3d import SelfAttention
+    torch.manual_seed(3)
+    at = SelfAttention(32, compute_dtype=torch.float32)
+    with torch.no_grad():
+        at.gamma.fill_(0.5)
+    sd = O.make_state({k: v.detach().clone() for k, v in at.state_dict().items()}, requires_grad=True)
+    x = torch.randn(2, 32, 48, 4, 4)
+    gy = torch.randn_like(x)
+    xr = x.clone().requires_grad_(True)
+    want = O.self_attention_3d(sd, "", xr)
+    want.backward(gy)
+    at = at.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    got = at(xg)
+    assert rel(got, want.detach()) < 2e-5
+    got.backward(gy.to(DEV))
+    assert rel(xg.grad, xr.grad) < 1e-4
+    for name, prm in at.named_parameters():
+        if name == "key_conv.bias":      # shifts every score of a query row alike -> zero gradient in exact arithmetic
+            assert float(prm.grad.abs().max()) < 1e-4 * float(at.key_conv.weight.grad.abs().max())
+            continue
+        assert rel(prm.grad, sd[name].grad) < 1e-4, name
+
+
 # ------------------------------------------------------------------ F6
 def cosine(a, b):
     a, b = a.detach().double().cpu().flatten(), torch.as_tensor(b).double().flatten()
