@@ -20,3 +20,8 @@ def sample_k_frames(data, video_length, k_sample, frame_ids=None):
 def vid_downsample(data):
     """[B,T,C,H,W] -> per-frame 2x2 average -> [B,C,T,H/2,W/2]"""
     return Fn.VidDownsample.apply(data)
+
+
+def denorm(x):
+    """utils.py:41-43: [-1, 1] -> [0, 1], clamped."""
+    return ((x + 1) / 2).clamp_(0, 1)

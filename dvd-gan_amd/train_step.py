@@ -19,7 +19,7 @@ from . import functional as Fn
 from .dist import GradExchange
 from .disc_nets import SpatialDiscriminator, TemporalDiscriminator
 from .gen_net import Generator
-from .helpers import draw_frame_ids, sample_k_frames, vid_downsample
+from .helpers import denorm, draw_frame_ids, sample_k_frames, vid_downsample
 from .optim import FlatAdam
 
 
@@ -175,6 +175,17 @@ class Trainer(object):
                          self.g_lr_scher.get_lr()[0]))
             if self.model_save_epoch and step % (self.model_save_epoch * steps_per_epoch) == 0:
                 self.save_models(step)
+
+    # ---- trainer.py:323-334: the sampling path (eval-mode G on fixed z / labels, BN running statistics), without
+    # the image-file side (torchvision save_image / tensorboard are host plumbing)
+    @torch.no_grad()
+    def sample(self, fixed_z, fixed_label):
+        """-> denorm(G(fixed_z, fixed_label)) [B, T, 3, H, W] in [0, 1]; G is put back in train mode, like the reference.
+        Note quirk 2: the spectral-norm u/v of G advance in eval mode as well."""
+        self.G.eval()
+        fake = self.G(fixed_z.to(self.device), fixed_label.to(self.device))
+        self.G.train()
+        return denorm(fake)
 
     # ---- trainer.py:337-343 / 375-382: reference-compatible checkpoints
     def save_models(self, step):

@@ -156,3 +156,25 @@ def test_step_at_128x128_frames_matches_oracle():
     got = [float(v.detach()) for v in tr.train_step(real, labels, draws)]
     want = O.train_step(st, real, labels, draws["z"], draws["z_class"], draws["perm_real"], draws["perm_fake"])
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
+
+
+def test_sampling_path_matches_oracle():
+    """trainer.py:323-334: eval-mode generator on fixed z / labels (BN running statistics) + utils.denorm, checked against
+    the oracle's eval-mode generator after one training step has moved the running statistics."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.train_step import Trainer
+    torch.manual_seed(21)
+    ch, T, k, B, ncls, zd = 2, 8, 4, 2, 3, 16
+    cfg = argparse.Namespace(adv_loss="hinge", z_dim=zd, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
+                             total_epoch=1, d_iters=1, batch_size=B, g_lr=5e-5, d_lr=5e-5, beta1=0.0, beta2=0.9,
+                             n_class=ncls, k_sample=k)
+    tr = Trainer([], cfg, device=torch.device("cuda", 0), compute_dtype=torch.float32)
+    tr.train_step(torch.rand(B, 3, T, 64, 64) * 2 - 1, torch.randint(0, ncls, (B,)))
+    sd = O.make_state({kk: v.detach().cpu().clone() for kk, v in tr.G.state_dict().items()}, requires_grad=False)
+    fixed_z, fixed_label = torch.randn(B, zd), torch.randint(0, ncls, (B,))
+    with torch.no_grad():
+        want = ((O.generator(sd, fixed_z, fixed_label, ch, T, training=False) + 1) / 2).clamp(0, 1)
+    got = tr.sample(fixed_z, fixed_label)
+    assert tr.G.training
+    assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    assert float((got.cpu() - want).abs().max()) < 2e-3
