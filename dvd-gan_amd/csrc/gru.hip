@@ -213,7 +213,8 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
     const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     static const long long target = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 1024;
     long long ns = (target + tiles - 1) / tiles;
-    if (ns > 16) ns = 16;
+    static const long long cap = getenv("DVD_NS_CAP") ? atoll(getenv("DVD_NS_CAP")) : 16;
+    if (ns > cap) ns = cap;
     if (ns > nk) ns = nk;
     if (ns < 1) ns = 1;
     return (int)ns;
