@@ -26,61 +26,114 @@ __device__ float blk_sum(float v, float* sh) {
     return t;
 }
 
+// Forward.  LDS: St [Nk][QB] scores -> probabilities (transposed: the QB values of one key are contiguous),
+// ql [QB][dqp] the block's query rows as floats, red [PARTS][QB][C8*8] partial outputs.
+//   scores : thread j owns key j: its row is read once with 16-byte loads, the QB query rows come from LDS
+//   softmax: one wave per query row, wave-reduced max / sum
+//   A v    : thread = (8-channel group, 4-row group, key part); 32 accumulators, one 16-byte v load and one
+//            16-byte LDS read of St per key; the key parts are folded through LDS
+// (the first version did one scalar load per multiply: 8 TF/s, 7 ms per step for D_s at N = 256)
 template <typename T, int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, int ldq, int dq, const T* kv, int ldk, int koff,
                                                        int voff, const T* x, int ldx, int C, const float* gamma, T* y,
                                                        T* att_out, float* A, int N, int Nk) {
-    extern __shared__ float S[];                   // [QB][Nk]
+    extern __shared__ float S[];
     const int f = blockIdx.y, i0 = blockIdx.x * QB, tid = threadIdx.x;
+    const int dqp = (dq + 7) & ~7, C8 = (C + 7) / 8;
+    float* St = S;                                  // [Nk][QB]
+    float* ql = S + (size_t)Nk * QB;                // [QB][dqp]
+    float* red = ql + QB * dqp;                     // [PARTS][QB][C8*8]
     const T* qf = qkv + (size_t)f * N * ldq;
     const T* kf = kv + (size_t)f * Nk * ldk;
+    for (int idx = tid; idx < QB * dqp; idx += 256) {
+        const int i = idx / dqp, d = idx - i * dqp;
+        ql[idx] = (i0 + i < N && d < dq) ? ldf(qf + (size_t)(i0 + i) * ldq + d) : 0.f;
+    }
+    __syncthreads();
     // ---- scores ----
-    for (int idx = tid; idx < QB * Nk; idx += 256) {
-        const int i = idx / Nk, j = idx - i * Nk;
-        float s = 0.f;
-        if (i0 + i < N) {
-            const T* q = qf + (size_t)(i0 + i) * ldq;
-            const T* k = kf + (size_t)j * ldk + koff;
-            for (int d = 0; d < dq; ++d) s += ldf(q + d) * ldf(k + d);
+    for (int j = tid; j < Nk; j += 256) {
+        float acc[QB];
+#pragma unroll
+        for (int i = 0; i < QB; ++i) acc[i] = 0.f;
+        const T* k = kf + (size_t)j * ldk + koff;
+        for (int d = 0; d < dqp; d += 8) {
+            float kk[8];
+            load8<T>(k + d, kk);                    // columns >= dq only ever meet zeros of ql
+#pragma unroll
+            for (int i = 0; i < QB; ++i) {
+                const float* q = ql + i * dqp + d;
+                acc[i] += q[0] * kk[0] + q[1] * kk[1] + q[2] * kk[2] + q[3] * kk[3] + q[4] * kk[4] + q[5] * kk[5] +
+                          q[6] * kk[6] + q[7] * kk[7];
+            }
         }
-        S[idx] = s;
+#pragma unroll
+        for (int i = 0; i < QB; ++i) St[j * QB + i] = acc[i];
     }
     __syncthreads();
     // ---- row softmax (one wave per row) ----
     const int wave = tid >> 6, lane = tid & 63;
     for (int i = wave; i < QB; i += 4) {
         float m = -INFINITY;
-        for (int j = lane; j < Nk; j += 64) m = fmaxf(m, S[i * Nk + j]);
+        for (int j = lane; j < Nk; j += 64) m = fmaxf(m, St[j * QB + i]);
         m = wave_max(m);
         float sum = 0.f;
-        for (int j = lane; j < Nk; j += 64) { const float e = expf(S[i * Nk + j] - m); S[i * Nk + j] = e; sum += e; }
+        for (int j = lane; j < Nk; j += 64) { const float e = expf(St[j * QB + i] - m); St[j * QB + i] = e; sum += e; }
         sum = wave_sum(sum);
         const float inv = 1.f / sum;
         for (int j = lane; j < Nk; j += 64) {
-            const float a = S[i * Nk + j] * inv;
-            S[i * Nk + j] = a;
+            const float a = St[j * QB + i] * inv;
+            St[j * QB + i] = a;
             if (A && i0 + i < N) A[((size_t)f * N + i0 + i) * Nk + j] = a;
         }
     }
     __syncthreads();
-    // ---- out = A v, 4 rows per thread ----
+    // ---- out = A v ----
+    constexpr int RG = QB / 4;                      // 4-row groups
+    const int items = C8 * RG;                      // (channel group, row group) pairs
+    const int parts = items >= 256 ? 1 : (256 / items > 4 ? 4 : 256 / items);
     const float g = *gamma;
-    for (int idx = tid; idx < (QB / 4) * C; idx += 256) {
-        const int ib = (idx / C) * 4, c = idx % C;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < Nk; ++j) {
-            const float vv = ldf(kf + (size_t)j * ldk + voff + c);
+    if (tid < items * parts) {
+        const int part = tid / items, it = tid - part * items;
+        const int cg = it % C8, rg = it / C8;
+        float acc[4][8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += S[(ib + r) * Nk + j] * vv;
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+        for (int j = part; j < Nk; j += parts) {
+            float vv[8];
+            load8<T>(kf + (size_t)j * ldk + voff + cg * 8, vv);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(St + j * QB + rg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[r][c] += a4[r] * vv[c];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + ib + r;
-            if (i >= N) continue;
-            const size_t o = ((size_t)f * N + i) * ldx + c;
-            if (att_out) stf(att_out + o, acc[r]);
-            stf(y + o, g * acc[r] + ldf(x + o));
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) red[((size_t)part * QB + rg * 4 + r) * (C8 * 8) + cg * 8 + c] = acc[r][c];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < QB * C8; idx += 256) {
+        const int i = idx / C8, cg = idx - i * C8;
+        if (i0 + i >= N) continue;
+        float o[8], xv[8], yv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = 0.f;
+        for (int part = 0; part < parts; ++part)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] += red[((size_t)part * QB + i) * (C8 * 8) + cg * 8 + c];
+        const size_t off = ((size_t)f * N + i0 + i) * ldx + cg * 8;
+        load8<T>(x + off, xv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool ok = cg * 8 + c < C;
+            o[c] = ok ? o[c] : 0.f;
+            yv[c] = ok ? g * o[c] + xv[c] : 0.f;
         }
+        if (att_out) store8<T>(att_out + off, o);
+        store8<T>(y + off, yv);
     }
 }
 
@@ -214,10 +267,13 @@ static int attention_fwd(int dtype, const void* q, int ldq, int dq, const void* 
                          void* stream) {
     if (!q || !kv || !x || !gamma || !y || frames <= 0 || N <= 0 || Nk <= 0 || dq <= 0 || C <= 0) return DVD_E_ARG;
     if (frames > 65535) return DVD_E_SHAPE;
-    const int qb = (size_t)16 * Nk * sizeof(float) <= 64 * 1024 ? 16 : 8;
-    if ((size_t)qb * Nk * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    if ((ldq & 7) || (ldk & 7) || (ldx & 7) || (koff & 7) || (voff & 7) || C > ldx) return DVD_E_SHAPE;   // 16-byte vectors
+    const int dqp = (dq + 7) & ~7, c8 = (C + 7) / 8 * 8;
+    auto lds_bytes = [&](int qb) { return ((size_t)qb * Nk + (size_t)qb * dqp + (size_t)4 * qb * c8) * sizeof(float); };
+    const int qb = lds_bytes(16) <= 64 * 1024 ? 16 : 8;
+    if (lds_bytes(qb) > 64 * 1024) return DVD_E_SHAPE;
     dim3 grid(cdiv(N, qb), (unsigned)frames);
-    const size_t sh = (size_t)qb * Nk * sizeof(float);
+    const size_t sh = lds_bytes(qb);
 #define ATT_FWD(QB_) BY_DTYPE(dtype, attn_fwd_kernel<T, QB_><<<grid, 256, sh, S_>>>((const T*)q, ldq, dq, (const T*)kv, ldk, koff, \
                                        voff, (const T*)x, ldx, C, gamma, (T*)y, (T*)att_out, A, N, Nk))
     if (qb == 16) ATT_FWD(16); else ATT_FWD(8);
