@@ -13,7 +13,7 @@ import torch.nn as nn
 from . import functional as Fn
 from . import kern as K
 from . import lib as L
-from .sn_layers import PlainConv, SpectralNormConv, _SNInner
+from .sn_layers import PlainConv, SpectralNormConv, _SNInner, clear_spectral_norm, prefetch_spectral_norm
 
 
 class SelfAttention(nn.Module):
@@ -149,6 +149,13 @@ class SpatialDiscriminator(_DiscBase):
         self._make_head(chn, n_class)
 
     def forward(self, x, class_id):
+        sn = prefetch_spectral_norm(self, self.compute_dtype)
+        try:
+            return self._forward(x, class_id)
+        finally:
+            clear_spectral_norm(sn)
+
+    def _forward(self, x, class_id):
         B, T, C_, H, W = x.shape
         xc = Fn.ToChannelsLast.apply(x.reshape(B * T, C_, H, W), self.compute_dtype, None)
         c1 = self.pre_conv[0](xc, act=L.ACT_RELU)
@@ -175,6 +182,13 @@ class TemporalDiscriminator(_DiscBase):
         self._make_head(chn, n_class)
 
     def forward(self, x, class_id):
+        sn = prefetch_spectral_norm(self, self.compute_dtype)
+        try:
+            return self._forward(x, class_id)
+        finally:
+            clear_spectral_norm(sn)
+
+    def _forward(self, x, class_id):
         xc = Fn.ToChannelsLast.apply(x, self.compute_dtype, None)            # [B,T,h,w,8]
         c1 = self.pre_conv[0](xc, act=L.ACT_RELU)
         p2 = Fn.Pool.apply(self.pre_conv[2](c1), 2)

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import functional as Fn
 from . import kern as K
 from . import lib as L
-from .sn_layers import ConditionalNorm, ConvParams, SpectralNormConv
+from .sn_layers import ConditionalNorm, ConvParams, SpectralNormConv, clear_spectral_norm, prefetch_spectral_norm
 
 
 class ConvGRUCell(nn.Module):
@@ -110,6 +110,13 @@ class Generator(nn.Module):
         self.colorize = SpectralNormConv(c2, 3, (3, 3))
 
     def forward(self, x, class_id):
+        sn = prefetch_spectral_norm(self, self.compute_dtype)    # SN + weight packing of all layers on the side stream
+        try:
+            return self._forward(x, class_id)
+        finally:
+            clear_spectral_norm(sn)
+
+    def _forward(self, x, class_id):
         B, T = x.shape[0], self.n_frames
         dev = x.device
         class_emb = Fn.Embedding.apply(self.embedding.weight, class_id.to(torch.int32))

@@ -281,9 +281,10 @@ def row_copy(src, idx, nrows_out, L_, scatter, out=None):
 
 
 # ------------------------------------------------------------------ spectral norm / small fp32 layers
-def sn_power_iter(w_bar, u, v):
-    """In-place u, v update; returns a fresh 1-element sigma tensor."""
-    sigma = torch.empty(1, dtype=torch.float32, device=w_bar.device)
+def sn_power_iter(w_bar, u, v, sigma=None):
+    """In-place u, v update; returns the 1-element sigma tensor (a fresh one unless `sigma` is given)."""
+    if sigma is None:
+        sigma = torch.empty(1, dtype=torch.float32, device=w_bar.device)
     h = w_bar.shape[0]
     L.check(L.lib().dvd_sn_power_iter(L.ptr(w_bar), h, w_bar.numel() // h, L.ptr(u), L.ptr(v), L.ptr(sigma), L.stream()))
     return sigma

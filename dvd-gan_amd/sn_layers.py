@@ -6,6 +6,7 @@ Reference: Module/Normalization.py (SpectralNorm :10-64, ConditionalNorm :66-88)
   <name>.{bn.running_mean, bn.running_var, bn.num_batches_tracked, embed.weight, embed.bias}
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -76,15 +77,66 @@ class SpectralNormConv(nn.Module):
         self.module = _SNInner((cout, cin) + self.ksize, cout)
         self.train_weights = True          # False: treat weights as constants (G step through D)
 
+        self._pre = None                   # (sigma, pack, event) prepared on the SN side stream for the next forward
+
+    def _alloc(self, dtype, device):
+        return (torch.empty(1, dtype=torch.float32, device=device),
+                K.PackedConv(dtype, self.cout, self.cin, self.ksize, device))
+
+    def _sn_and_pack(self, sigma, pack):
+        """One power iteration (u, v updated in place), sigma, and W_bar / sigma written into the MFMA operand images."""
+        m = self.module
+        K.sn_power_iter(m.weight_bar.data, m.weight_u.data, m.weight_v.data, sigma)
+        pack.fill(m.weight_bar.data, sigma)
+
     def forward(self, x, *, res=None, act=L.ACT_NONE, up2=False, relu_in=False):
         m = self.module
-        sigma = K.sn_power_iter(m.weight_bar.data, m.weight_u.data, m.weight_v.data)
+        if self._pre is not None:          # prepared by prefetch_spectral_norm on the side stream
+            sigma, pack, ev = self._pre
+            self._pre = None
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            sigma, pack = self._alloc(x.dtype, x.device)
+            self._sn_and_pack(sigma, pack)
         spec = Fn.ConvSpec(self.ksize, self.cout, self.cin, act=act, up2=up2, relu_in=relu_in,
                            sn=(m.weight_u.data, m.weight_v.data))
         spec.sigma = sigma
-        spec.pack = K.PackedConv(x.dtype, self.cout, self.cin, self.ksize, x.device).fill(m.weight_bar.data, sigma)
+        spec.pack = pack
         w, b = (m.weight_bar, m.bias) if self.train_weights else (m.weight_bar.detach(), m.bias.detach())
         return Fn.Conv.apply(x, w, b, res, spec)
+
+
+_SN_STREAMS = {}
+
+
+def prefetch_spectral_norm(net, dtype):
+    """Spectral norm of every SN conv of `net` for the forward that is starting: power iteration + sigma + the
+    sigma-normalised MFMA weight images, all issued on a side stream (the reference does this inside each layer's
+    forward, Normalization.py:19-31,61-63; u / v advance exactly once per network forward either way, quirk 2).
+    Outputs are allocated on the caller's stream; each layer waits for its own event before its convolution.
+    Returns the modules so the caller can drop unused preparations (`clear_spectral_norm`)."""
+    mods = [m for m in net.modules() if isinstance(m, SpectralNormConv)]
+    if not mods or not torch.cuda.is_available() or os.environ.get("DVD_SN_SIDE", "1") == "0":
+        return mods
+    dev = mods[0].module.weight_bar.device
+    main = torch.cuda.current_stream(dev)
+    side = _SN_STREAMS.get(dev.index)
+    if side is None:
+        side = _SN_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    bufs = [m._alloc(dtype, dev) for m in mods]          # allocated (and zero-filled) in main-stream order
+    side.wait_stream(main)                               # weights, u, v and the fresh buffers are current
+    with torch.cuda.stream(side):
+        for m, (sigma, pack) in zip(mods, bufs):
+            m._sn_and_pack(sigma, pack)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            m._pre = (sigma, pack, ev)
+    return mods
+
+
+def clear_spectral_norm(mods):
+    for m in mods:
+        m._pre = None
 
 
 class PlainConv(nn.Module):
