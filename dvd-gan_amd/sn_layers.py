@@ -81,7 +81,7 @@ class SpectralNormConv(nn.Module):
 
     def _alloc(self, dtype, device):
         return (torch.empty(1, dtype=torch.float32, device=device),
-                K.PackedConv(dtype, self.cout, self.cin, self.ksize, device))
+                K.PackedConv(dtype, self.cout, self.cin, self.ksize, device, single_fill=True))
 
     def _sn_and_pack(self, sigma, pack):
         """One power iteration (u, v updated in place), sigma, and W_bar / sigma written into the MFMA operand images."""
