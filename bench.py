@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_GFLOP_PER_CLIP = {(32, 48, 64): 8148.5, (32, 48, 128): 32608.6}       # SURVEY.md section 8(d) / BASELINE.md section 3
+PEAK_F32_MFMA_TFLOPS = 157.3     # f32-input MFMA = vector rate (MI355X_MICROARCH.md, matrix cores table); exact mode
 PEAK_BF16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
@@ -147,14 +148,15 @@ def main():
                          "avg_us": tms.value * 1e3 / max(n, 1), "gflop_per_launch": fl.value / max(n, 1) / 1e9}
         F = F_GFLOP_PER_CLIP.get((a.ch, a.frames, a.size))
         dom = res["conv_igemm"]
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "kernel": "conv_halo_kernel + conv_igemm_kernel <bf16> (forward + backward-data convolutions)" if a.dtype == "bf16" else "conv_halo_kernel + conv_igemm_kernel <f32>",
-                "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic("conv_igemm"),
+                "achieved": round(dom["tflops"], 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(dom["tflops"] / peak, 4), "traffic": hbm_traffic("conv_igemm"),
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),
                 "gflop_per_launch": round(dom["gflop_per_launch"], 2), "kernel_ms_per_step": round(dom["ms"], 1),
                 "wgrad": {k: round(v, 2) if isinstance(v, float) else v for k, v in res["conv_wgrad"].items()},
                 "step_achieved": round(value / world * F / 1e3, 1) if F else None,
-                "step_frac": round(value / world * F / 1e3 / PEAK_BF16_TFLOPS, 4) if F else None}
+                "step_frac": round(value / world * F / 1e3 / peak, 4) if F else None}
     if rank == 0:
         out = {"metric": "clips/sec per G+Ds+Dt step, 48x64x64 UCF-101 synth" if a.size == 64 else f"clips/sec per G+Ds+Dt step, {a.frames}x{a.size}x{a.size} Kinetics-600-shaped synth", "value": round(value, 3), "unit": "clips/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
