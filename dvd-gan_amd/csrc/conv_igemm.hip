@@ -19,8 +19,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, NT = 256;
-constexpr int ROWB = 80;                 // bytes per LDS tile row
-constexpr int TILEB = BM * ROWB;         // 10240 B per operand tile
+constexpr int TILEB = BM * 80;            // f32 wgrad: 10240 B per operand tile ([16 rows][WG_LD floats] fits)
 constexpr int WG_LD = 132;               // f32 wgrad LDS row length in floats (128 + 4 pad)
 
 __device__ __forceinline__ u32x4 relu16_f32(u32x4 v) {
@@ -39,40 +38,6 @@ __device__ __forceinline__ u32x4 relu16_bf16(u32x4 v) {
 template <typename T> __device__ __forceinline__ u32x4 relu16(u32x4 v);
 template <> __device__ __forceinline__ u32x4 relu16<float>(u32x4 v) { return relu16_f32(v); }
 template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) { return relu16_bf16(v); }
-
-// acc[tm][tn] += A(64 rows of this wave) x B(64 cols of this wave) over one 64-byte K chunk.
-// As / Bs point at this lane's row (lane&31) of the wave's first 32-row sub-tile.
-template <typename T>
-__device__ __forceinline__ void mma_rowmajor(const char* As, const char* Bs, int lane, f32x16 (&acc)[2][2]) {
-    const int kh = lane >> 5;
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int o = kk * 32 + kh * 16;
-            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + o);
-            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As + 32 * ROWB + o);
-            bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + o);
-            bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs + 32 * ROWB + o);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const int o = (kk * 2 + kh) * 4;
-            float a0 = *reinterpret_cast<const float*>(As + o);
-            float a1 = *reinterpret_cast<const float*>(As + 32 * ROWB + o);
-            float b0 = *reinterpret_cast<const float*>(Bs + o);
-            float b1 = *reinterpret_cast<const float*>(Bs + 32 * ROWB + o);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-}
 
 // ============================================================================ forward
 struct ConvK {
