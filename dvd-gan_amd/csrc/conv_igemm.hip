@@ -1502,7 +1502,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     if (msplit < 1) {   // auto: ~16 workgroups per CU, every workgroup keeping >= 4k rows of reduction.  Swept on the
                         // full step with the workspace reduction (ms of wgrad per step): (1024,8192) 292,
                         // (1536,8192) 267, (3072,4096) 247, (4096,4096) 243, (6144,4096) 242, (8192,2048) 252
-        static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 4096;
+        static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 2048;   // re-swept with whole-round grids: 4096 185.6, 2048 183.2, 1024 183.5 ms
         static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 4096;
         static const long long tgt_row = getenv("DVD_WGR_TGT") ? atoll(getenv("DVD_WGR_TGT")) : 1536;   // swept with whole-round grids: 1024 187.7, 1536 185.1, 2048 190.8, 3072 192.2 ms
         const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps);
