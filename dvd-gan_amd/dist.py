@@ -3,9 +3,9 @@
 The reference only has nn.DataParallel (trainer.py:353-359): single process, gradients summed
 onto GPU 0, batch-norm statistics and SN power iterations per replica.  Here each rank owns
 clips [r*B/N, (r+1)*B/N) of the global batch; after each of the three backward passes the flat
-gradient buffer of that network (optim.FlatAdam.grad) is all-reduced ONCE on a side stream, so
-the D_s exchange overlaps the D_t forward/backward and the D_t exchange overlaps the first
-convolutions of the generator step.  Batch-norm statistics stay per replica (= DataParallel
+gradient buffer of that network (optim.FlatAdam.grad) is all-reduced on a side stream: D_s in one piece
+(it overlaps the D_t forward/backward), the generator's in buckets that start as soon as the backward
+pass has left the corresponding ConvGRU stage (the buffer's tail is final first).  Batch-norm statistics stay per replica (= DataParallel
 semantics); SN u/v need no exchange because weights are identical on every rank.
 """
 import os
@@ -57,10 +57,33 @@ class GradExchange:
             ev.record(self.stream)
         self.pending[key] = ev
 
+    def start_range(self, key, flat_grad, lo, hi):
+        """Begin averaging flat_grad[lo:hi] (a bucket); several ranges may be pending under one key.  Every rank must
+        issue the same ranges in the same order."""
+        if self.world == 1 or hi <= lo:
+            return
+        view = flat_grad[lo:hi]
+        if self.stream is None:
+            dist.all_reduce(view)
+            view.div_(self.world)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(view)
+            view.div_(self.world)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.pending.setdefault(key, [])
+        if not isinstance(self.pending[key], list):
+            self.pending[key] = [self.pending[key]]
+        self.pending[key].append(ev)
+
     def finish(self, key):
         ev = self.pending.pop(key, None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        if ev is None:
+            return
+        for e in (ev if isinstance(ev, list) else [ev]):
+            torch.cuda.current_stream().wait_event(e)
 
 
 def shard(t, rank, world):

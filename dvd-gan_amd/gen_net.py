@@ -108,6 +108,9 @@ class Generator(nn.Module):
             GResBlock(c4, c4, nc, 1), GResBlock(c4, c2, nc),
         ])
         self.colorize = SpectralNormConv(c2, 3, (3, 3))
+        self.dp_hooks = False                       # data-parallel trainer sets it: stage-boundary gradient hooks
+        self.grad_ready_hook = None                 # callable(first finished module index), armed around backward
+        self.grad_ready_stages = (2, 5, 8)          # after each [ConvGRU, GResBlock, GResBlock] group but the last
 
     def forward(self, x, class_id):
         sn = prefetch_spectral_norm(self, self.compute_dtype)    # SN + weight packing of all layers on the side stream
@@ -133,6 +136,9 @@ class Generator(nn.Module):
                 y = m.run(y, T, shared_x=(k == 0))[-1]
             else:
                 y = m.run(y, zc, samp)
+            if self.dp_hooks and y.requires_grad and k in self.grad_ready_stages:
+                # fires when the backward pass has produced d/dy: every module after k has all its gradients queued
+                y.register_hook(lambda g_, k_=k: self.grad_ready_hook(k_ + 1) if self.grad_ready_hook else None)
         y = self.colorize(y, relu_in=True, act=L.ACT_TANH)
         out = Fn.FromChannelsLast.apply(y, 3, (B, T))          # t-major frames -> b-major [B*T,3,H,W]
         return out.view(B, T, 3, out.shape[-2], out.shape[-1])

@@ -77,6 +77,15 @@ class Trainer(object):
     def select_opt_schr(self):
         betas = (self.beta1, self.beta2)
         self.g_optimizer = FlatAdam(self.G.parameters(), self.g_lr, betas)
+        self.G.dp_hooks = self.exchange.world > 1
+        # offset of the first trainable parameter of generator module conv.k in the flat buffers (gradient buckets)
+        self._g_bounds, off = {}, 0
+        for name, prm in self.G.named_parameters():
+            if not prm.requires_grad:
+                continue
+            if name.startswith("conv."):
+                self._g_bounds.setdefault(int(name.split(".")[1]), off)
+            off += prm.numel()
         self.ds_optimizer = FlatAdam(self.D_s.parameters(), self.d_lr, betas)
         self.dt_optimizer = FlatAdam(self.D_t.parameters(), self.d_lr, betas)
         if self.lr_schr not in ("const", "step", "exp", "multi"):
@@ -146,8 +155,19 @@ class Trainer(object):
         g_t_loss = self.calc_loss(self.D_t(fake_d, z_class), True)
         self._freeze_d(False)
         self.g_optimizer.zero_grad()
+        if ex.world > 1:
+            # bucketed exchange: the tail of the flat gradient buffer (last modules) is final first
+            self._g_hi = self.g_optimizer.grad.numel()
+
+            def on_ready(first_done, self=self, ex=ex):
+                lo = self._g_bounds[first_done]
+                ex.start_range("G", self.g_optimizer.grad, lo, self._g_hi)
+                self._g_hi = min(self._g_hi, lo)
+            self.G.grad_ready_hook = on_ready
         (g_s_loss + g_t_loss).backward()
-        ex.start("G", self.g_optimizer.grad)
+        if ex.world > 1:
+            self.G.grad_ready_hook = None
+            ex.start_range("G", self.g_optimizer.grad, 0, self._g_hi)
         ex.finish("G")
         self.g_optimizer.step()
         self.g_lr_scher.step()
