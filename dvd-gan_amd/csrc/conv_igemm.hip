@@ -1011,7 +1011,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
 //   LDS:   dy [32 rows][64*WM ch] (+64 B pad, transposing reads as in conv_wgrad_kernel);
 //          x  [2 halves of 32 ch][48 rows][64 B]: the 4 consecutive rows a ds_read_b64_tr_b16 pass touches are
 //             256 contiguous bytes (conflict-free without a swizzle) and a tap is a +64-byte immediate offset.
-template <int WM, int KW, bool RELU>
+// UP2: the convolution reads a nearest-x2 upsampled input (GResBlock.py:57-58): the footprint is kept in INPUT
+// coordinates (half the columns), tap ix of step pixel pk reads row ((pk + ix - pad) >> 1) + 1 of it.
+template <int WM, int KW, bool RELU, bool UP2 = false>
 __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
     constexpr int NTt = WM * 128, BMc = WM * 64;
     constexpr int RSA = BMc * 2 + 64;
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
 #pragma unroll
             for (int t = 0; t < KW; ++t) acc[a][t] = zacc;
     }
-    const int xbase_row = max(0, m_begin - p.maxshift);
+    const int xbase_row = UP2 ? (m_begin >> (p.logW + p.logH)) * p.Hin * p.Win : max(0, m_begin - p.maxshift);
     const size_t xbase_b = (size_t)xbase_row * p.ldx * 2, ybase_b = (size_t)m_begin * p.ldy * 2;
     const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -1057,7 +1059,9 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.dy + ybase_b), 0, yleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)yleft, 0x00020000);
     // step geometry: 32 pixels = one 32-pixel segment of a line (W >= 32), two 16-pixel lines or four 8-pixel lines
-    const int segw = min(p.W, 32), logsegw = min(p.logW, 5), fpr = segw + KW - 1, frows = (32 >> logsegw) * fpr;
+    constexpr int cpad = (pad + 1) >> 1;
+    const int segw = min(p.W, 32), logsegw = min(p.logW, 5);
+    const int fpr = UP2 ? (segw >> 1) + 2 : segw + KW - 1, frows = (32 >> logsegw) * fpr;
     // dy loader: NPA 16-byte chunks per thread
     constexpr int CPRA = BMc / 8, RPPA = NTt / CPRA, NPA = 32 / RPPA;
     const int rra = tid / CPRA, cka = tid % CPRA;
@@ -1096,10 +1100,19 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
         }
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
-            const int yy = y + xseg[i] + dyl, xx = x0 + xj[i] - pad;
-            const bool ok = xcv[i] && tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)(frow0 + (yy << p.logW) + xx - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i]
-                                    : 0xffffffffu;
+            const int yy = y + xseg[i] + dyl;                       // output line the tap row looks at
+            bool ok = xcv[i] && tok && (unsigned)yy < (unsigned)p.H;
+            int row;
+            if (UP2) {
+                const int xin = (x0 >> 1) - cpad + xj[i];
+                ok = ok && (unsigned)xin < (unsigned)p.Win;
+                row = (mk >> (p.logW + p.logH)) * (p.Hin * p.Win) + (yy >> 1) * p.Win + xin;
+            } else {
+                const int xx = x0 + xj[i] - pad;
+                ok = ok && (unsigned)xx < (unsigned)p.W;
+                row = frow0 + (yy << p.logW) + xx;
+            }
+            const unsigned off = ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i] : 0xffffffffu;
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
         }
     };
@@ -1140,15 +1153,19 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
         return __builtin_bit_cast(bf16x8, f);
     };
     // footprint row of step pixel pk (before the tap offset): line s of a multi-line step starts at row s * fpr
-    int xoffs[2][2];                                             // [k half][lo / hi 4-row block]
+    constexpr int NT_ = UP2 ? KW : 1;                            // x2 fold: the row depends on the tap's parity
+    int xoffs[2][2][NT_];                                        // [k half][lo / hi 4-row block][tap]
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-            const int pk = kb * 16 + frow + hl * 4;
-            const int fr = (pk >> logsegw) * fpr + (pk & (segw - 1));
-            xoffs[kb][hl] = TA_BYTES + wn * XHALF + fr * 64 + fcol2;
-        }
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int t = 0; t < NT_; ++t) {
+                const int pk = kb * 16 + frow + hl * 4;
+                const int px_ = pk & (segw - 1);
+                const int fr = (pk >> logsegw) * fpr + (UP2 ? ((px_ + t - pad) >> 1) + cpad : px_);
+                xoffs[kb][hl][t] = TA_BYTES + wn * XHALF + fr * 64 + fcol2;
+            }
     const int aoff = frow * RSA + fcol2 + (wm * 64) * 2;
     auto mma1 = [&](const char* st) __attribute__((always_inline)) {
         constexpr int NU = 2 * KW;                               // units: (k half, tap), 2 MFMAs each
@@ -1162,7 +1179,8 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
         };
         auto ldB = [&](int u) __attribute__((always_inline)) {
             const int kb = u / KW, t = u % KW;
-            fb[u] = tr2(st + xoffs[kb][0] + t * 64, st + xoffs[kb][1] + t * 64);
+            if constexpr (UP2) fb[u] = tr2(st + xoffs[kb][0][t], st + xoffs[kb][1][t]);
+            else fb[u] = tr2(st + xoffs[kb][0][0] + t * 64, st + xoffs[kb][1][0] + t * 64);
         };
         ldA(0); ldB(0); ldB(1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1480,7 +1498,8 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         else if (d->Cin_real >= 192) tb = 4;
     }
     static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
-    mode = (use_row && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && !d->up2 && d->W >= 8 && (d->H * d->W) % 32 == 0) ? 1 : 0;
+    mode = (use_row && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) && d->W >= 8 &&
+            (d->H * d->W) % 32 == 0) ? 1 : 0;
     if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
         const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
         static const int force_wm = getenv("DVD_WGR_WM") ? atoi(getenv("DVD_WGR_WM")) : 0;
@@ -1553,10 +1572,16 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
 #define LAUNCH_ROW(WM_, KW_)                                                                        \
         do { if (d->relu_in) conv_wgrad_row_kernel<WM_, KW_, true><<<grid, WM_ * 128, 0, st>>>(p);      \
              else conv_wgrad_row_kernel<WM_, KW_, false><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
+#define LAUNCH_ROW_UP(WM_)                                                                          \
+        do { if (d->relu_in) conv_wgrad_row_kernel<WM_, 3, true, true><<<grid, WM_ * 128, 0, st>>>(p);  \
+             else conv_wgrad_row_kernel<WM_, 3, false, true><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
+        if (d->up2) { if (ta == 4) LAUNCH_ROW_UP(4); else if (ta == 2) LAUNCH_ROW_UP(2); else LAUNCH_ROW_UP(1); }
+        else
         if (ta == 4)      { if (d->kw == 5) LAUNCH_ROW(4, 5); else LAUNCH_ROW(4, 3); }
         else if (ta == 2) { if (d->kw == 5) LAUNCH_ROW(2, 5); else LAUNCH_ROW(2, 3); }
         else              { if (d->kw == 5) LAUNCH_ROW(1, 5); else LAUNCH_ROW(1, 3); }
 #undef LAUNCH_ROW
+#undef LAUNCH_ROW_UP
         if (p.ws) {
             WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, d->kw, p.Cout, p.Cin_real,
                         p.s_co, p.s_ci, p.s_tap};
