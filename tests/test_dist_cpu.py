@@ -42,8 +42,15 @@ def _worker(rank, world, port, out):
     assert xs.shape[0] == 1
     _, flat = _ds_grads(g, xs, cs)
     ex = D.GradExchange()
+    bucketed = flat.clone()
     ex.start("Ds", flat)
     ex.finish("Ds")
+    # the generator's exchange goes in buckets (tail of the flat buffer first): same result as one all-reduce
+    n = bucketed.numel()
+    for lo, hi in ((2 * n // 3, n), (n // 3, 2 * n // 3), (0, n // 3)):
+        ex.start_range("G", bucketed, lo, hi)
+    ex.finish("G")
+    assert torch.equal(bucketed, flat)
     out[rank] = flat.numpy().copy()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
