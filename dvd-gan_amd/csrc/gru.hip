@@ -28,7 +28,7 @@ __global__ void gru_gates_ur_kernel(const float* ws, int ns, const T* gx, int ld
     const int cg = h / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * cg) return;
-    const long long row = i / cg;
+    const long long row = (unsigned)i / (unsigned)cg;          // M * cg < 2^31 (checked by the layer entry points)
     const int c = (int)(i - row * cg) * 8;
     float pu[8], pr[8], hp[8];
     load8<T>(gx + (size_t)row * ldg + c, pu);
@@ -60,7 +60,7 @@ __global__ void gru_out_kernel(const float* ws, int ns, const T* gx, int ldg, co
     const int cg = h / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * cg) return;
-    const long long row = i / cg;
+    const long long row = (unsigned)i / (unsigned)cg;          // M * cg < 2^31 (checked by the layer entry points)
     const int c = (int)(i - row * cg) * 8;
     float po[8], hp[8], uu[8];
     load8<T>(gx + (size_t)row * ldg + 2 * h + c, po);
@@ -94,7 +94,7 @@ __global__ void gru_bwd_out_kernel(const T* dh_out, float* carry, const float* w
     const int cg = h / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * cg) return;
-    const long long row = i / cg;
+    const long long row = (unsigned)i / (unsigned)cg;          // M * cg < 2^31 (checked by the layer entry points)
     const int c = (int)(i - row * cg) * 8;
     const size_t off = (size_t)row * h + c;
     float dh[8], t8[8], uu[8], oo[8], hp[8], dpu[8], dpo[8];
@@ -131,7 +131,7 @@ __global__ void gru_bwd_r_kernel(float* carry, const float* ws, int ns, const T*
     const int cg = h / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * cg) return;
-    const long long row = i / cg;
+    const long long row = (unsigned)i / (unsigned)cg;          // M * cg < 2^31 (checked by the layer entry points)
     const int c = (int)(i - row * cg) * 8;
     const size_t off = (size_t)row * h + c;
     float dhr[8], t8[8], rr[8], hp[8], cy[8];
@@ -227,6 +227,7 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
     if (d->hidden & 7) return DVD_E_SHAPE;
     const int h = d->hidden, ntaps = d->k * d->k;
     const long long M = (long long)d->B * d->H * d->W;
+    if (M * (d->hidden / 8) >= (1ll << 31)) return DVD_E_SHAPE;
     const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
     const size_t step = (size_t)M * h * esz;
     const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, 2 * h, h, ntaps);
@@ -282,6 +283,7 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
     if (d->hidden & 7) return DVD_E_SHAPE;
     const int h = d->hidden, ntaps = d->k * d->k;
     const long long M = (long long)d->B * d->H * d->W;
+    if (M * (d->hidden / 8) >= (1ll << 31)) return DVD_E_SHAPE;
     const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
     const size_t step = (size_t)M * h * esz;
     const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);        // d(hr)  = convT(d pre_o)
