@@ -1,9 +1,8 @@
-"""Import shim: the package sources live in ./dvd-gan_amd/ (a directory name Python cannot
-import directly).  `import dvd_gan_amd` resolves every submodule from there."""
-import os as _os
+"""dvd_gan_amd -- MI355X-native DVD-GAN training hot path.
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "dvd-gan_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+Host side is Python on PyTorch-ROCm (device memory, streams, torch.distributed); every
+arithmetic op of the G / D_s / D_t step runs in hand-written gfx950 kernels behind the C ABI
+declared in include/dvdgan_hip.h (csrc/libdvdgan_hip.so).  There is no CPU or eager fallback:
+`dvd_gan_amd.lib.lib()` raises if the library is missing.
+"""
+__version__ = "0.1.0"
