@@ -148,14 +148,24 @@ def gresblock(sd, pfx, x, cond, upsample, training=True):
 GEN_STACK = ("gru", "res1", "res2") * 4      # Generator.py:38-55: [ConvGRU, GResBlock, GResBlock(up)] x 4
 
 
-def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True):
-    """Generator.forward, Generator.py:63-120 (hierar_flag=False)."""
+def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True, taps=None):
+    """Generator.forward, Generator.py:63-120 (hierar_flag=False).
+    taps (test aid): a list that receives the input of the first module followed by the output of each of the 12
+    modules of `self.conv` ([B*T, C, S, S], b-major frames), each with retain_grad() so a later backward leaves the
+    gradient flowing through that point on the tensor."""
     B, T = z.shape[0], n_frames
     class_emb = F.embedding(class_id, sd["embedding.weight"])
     zc = torch.cat([z, class_emb], 1)
     y = F.linear(zc, sd["affine_transfrom.weight"], sd["affine_transfrom.bias"])
     y = y.view(-1, 8 * ch, latent_dim, latent_dim)
     cond = zc.repeat(T, 1)                    # Generator.py:109-110: t-major rows (quirk 1)
+
+    def tap(v):
+        if taps is not None:
+            if v.requires_grad:
+                v.retain_grad()
+            taps.append(v)
+    tap(y)
     for k, kind in enumerate(GEN_STACK):
         pfx = f"conv.{k}."
         if kind == "gru":
@@ -168,6 +178,7 @@ def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True):
             y = torch.stack(frames, 1).reshape(B * T, *frames[0].shape[1:])    # b-major frames
         else:
             y = gresblock(sd, pfx, y, cond, 1 if kind == "res1" else 2, training)
+        tap(y)
     y = F.relu(y)
     y = F.conv2d(y, sn_weight(sd, "colorize.module."), sd["colorize.module.bias"], padding=1)
     y = torch.tanh(y)
@@ -330,30 +341,53 @@ class TrainState:
                 p.grad = None
 
 
-def train_step(st, real_videos, real_labels, z, z_class, perm_real, perm_fake):
+def snapshot_grads(st):
+    """Test aid: record every parameter gradient at the moment its optimizer steps (the gradients the reference's
+    three `optimizer.step()` calls consume, trainer.py:253,269,307).  Returns {"Ds" | "Dt" | "G": {key: grad}}, filled
+    by the next train_step."""
+    snaps = {}
+    for tag, opt in (("Ds", st.ds_opt), ("Dt", st.dt_opt), ("G", st.g_opt)):
+        def stepper(opt=opt, tag=tag, orig=opt.step):
+            snaps[tag] = {k: p.grad.detach().clone() for k, p in opt.params.items() if p.grad is not None}
+            orig()
+        opt.step = stepper
+    return snaps
+
+
+def train_step(st, real_videos, real_labels, z, z_class, perm_real, perm_fake, rec=None):
     """trainer.py:213-307 with d_iters=1.  real_videos: [B,3,T,H,W]; RNG draws are passed in
     the order the reference consumes them: perm_real, z, z_class, perm_fake.
-    Returns the six loss terms [ds_real, ds_fake, dt_real, dt_fake, g_s, g_t]."""
+    Returns the six loss terms [ds_real, ds_fake, dt_real, dt_fake, g_s, g_t].
+    rec (test aid): a dict that receives the generator taps (`generator(..., taps=)`), the generated clips and the six
+    raw discriminator outputs, for teacher-forced comparisons of single modules."""
+    taps = [] if rec is not None else None
     real = real_videos.permute(0, 2, 1, 3, 4).contiguous()                      # :227
     real_s = sample_k_frames(real, frame_ids_from_perm(perm_real, st.k))           # :233
-    fake = generator(st.G, z, z_class, st.ch, st.T, st.latent_dim)               # :239
+    fake = generator(st.G, z, z_class, st.ch, st.T, st.latent_dim, taps=taps)    # :239
     fake_s = sample_k_frames(fake, frame_ids_from_perm(perm_fake, st.k))           # :242
     # ---- D_s ----                                                                 :243-253
-    ds_real = adv_loss(spatial_disc(st.Ds, real_s, real_labels), True, st.adv)
-    ds_fake = adv_loss(spatial_disc(st.Ds, fake_s.detach(), z_class), False, st.adv)
+    o_sr, o_sf = spatial_disc(st.Ds, real_s, real_labels), spatial_disc(st.Ds, fake_s.detach(), z_class)
+    ds_real = adv_loss(o_sr, True, st.adv)
+    ds_fake = adv_loss(o_sf, False, st.adv)
     st.zero_grad()
     (ds_real + ds_fake).backward()
     st.ds_opt.step()
     # ---- D_t ----                                                                 :256-269
     real_d, fake_d = vid_downsample(real), vid_downsample(fake)
-    dt_real = adv_loss(temporal_disc(st.Dt, real_d, real_labels), True, st.adv)
-    dt_fake = adv_loss(temporal_disc(st.Dt, fake_d.detach(), z_class), False, st.adv)
+    o_tr, o_tf = temporal_disc(st.Dt, real_d, real_labels), temporal_disc(st.Dt, fake_d.detach(), z_class)
+    dt_real = adv_loss(o_tr, True, st.adv)
+    dt_fake = adv_loss(o_tf, False, st.adv)
     st.zero_grad()
     (dt_real + dt_fake).backward()
     st.dt_opt.step()
     # ---- G (on the UPDATED discriminators; loss uses the "real" form) ----        :296-307
-    g_s = adv_loss(spatial_disc(st.Ds, fake_s, z_class), True, st.adv)
-    g_t = adv_loss(temporal_disc(st.Dt, fake_d, z_class), True, st.adv)
+    o_gs, o_gt = spatial_disc(st.Ds, fake_s, z_class), temporal_disc(st.Dt, fake_d, z_class)
+    g_s = adv_loss(o_gs, True, st.adv)
+    g_t = adv_loss(o_gt, True, st.adv)
+    if rec is not None:
+        fake.retain_grad()
+        rec.update(taps=taps, fake=fake, real_s=real_s, fake_s=fake_s, real_d=real_d, fake_d=fake_d,
+                   d_out={"ds_real": o_sr, "ds_fake": o_sf, "dt_real": o_tr, "dt_fake": o_tf, "g_s": o_gs, "g_t": o_gt})
     st.zero_grad()
     (g_s + g_t).backward()
     st.g_opt.step()

@@ -360,11 +360,15 @@ def f8_helpers(R):
 
 # ----------------------------------------------------------------------------- F9 / F10
 def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr=5e-5,
-                grads_of=(), n_batches=None):
+                grads_of=(), n_batches=None, synth_big=False, grad_head=None):
     """Drive the unmodified reference Trainer.train() (trainer.py:189-307) on CPU and
     record every RNG draw, the six loss terms per step, named gradients and parameter
-    checksums at each optimizer.step()."""
+    checksums at each optimizer.step().
+    synth_big: every floating-point state tensor with >= synth.BIG elements and the input clips are set to the
+    closed-form values of tests/golden/synth.py BEFORE the reference runs, and are not stored.
+    grad_head: store only the first `grad_head` elements (flattened) of each named gradient."""
     import trainer as TR
+    import synth
     import torch.nn as nn
     nn.Module.cuda = lambda self, *a, **kw: self          # trainer.py:349-351 call .cuda()
     torch.manual_seed(seed)
@@ -378,16 +382,25 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
         log_epoch=10 ** 6, sample_epoch=10 ** 6, model_save_epoch=10 ** 6, version="g",
         gpus=[], parallel=False)
     gen = torch.Generator().manual_seed(seed + 1)
-    loader = [((torch.rand(B, 3, T, 64, 64, generator=gen) * 2 - 1),
-               torch.randint(0, n_class, (B,), generator=gen))
-              for _ in range(steps if n_batches is None else n_batches)]
+    nb_ = steps if n_batches is None else n_batches
+    if synth_big:
+        loader = [(torch.from_numpy(synth.uniform(f"real.{i}", (B, 3, T, 64, 64))),
+                   torch.randint(0, n_class, (B,), generator=gen)) for i in range(nb_)]
+    else:
+        loader = [((torch.rand(B, 3, T, 64, 64, generator=gen) * 2 - 1),
+                   torch.randint(0, n_class, (B,), generator=gen)) for _ in range(nb_)]
     tr = TR.Trainer(loader, cfg)
     st = {}
-    put_sd(st, "G.sd0", tr.G)
-    put_sd(st, "Ds.sd0", tr.D_s)
-    put_sd(st, "Dt.sd0", tr.D_t)
+    for net, tag in ((tr.G, "G"), (tr.D_s, "Ds"), (tr.D_t, "Dt")):
+        for kk, v in net.state_dict().items():
+            if synth_big and v.is_floating_point() and v.numel() >= synth.BIG:
+                v.copy_(torch.from_numpy(synth.weight(tag + "." + kk, tuple(v.shape))))    # state_dict tensors alias the parameters
+            else:
+                st[f"{tag}.sd0.{kk}"] = npy(v)
     for i, (v, l) in enumerate(loader):
-        st[f"in.real.{i}"], st[f"in.labels.{i}"] = npy(v), npy(l)
+        if not synth_big:
+            st[f"in.real.{i}"] = npy(v)
+        st[f"in.labels.{i}"] = npy(l)
 
     draws = {"randperm": [], "randn": [], "randint": []}
     o_perm, o_randn, o_randint = torch.randperm, torch.randn, torch.randint
@@ -412,8 +425,8 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
         o_step = opt.step
 
         def stepper(*a, **kw):
-            g = {kk: npy(p.grad) for kk, p in net.named_parameters()
-                 if p.grad is not None and kk in grads_of}
+            g = {kk: (npy(p.grad) if grad_head is None else npy(p.grad.reshape(-1)[:grad_head]))
+                 for kk, p in net.named_parameters() if p.grad is not None and kk in grads_of}
             gsum = {kk: float(p.grad.double().abs().sum()) for kk, p in net.named_parameters()
                     if p.grad is not None}
             r = o_step(*a, **kw)
@@ -452,6 +465,7 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
     put_state(st, "Dt.sd1", tr.D_t)
     st["meta.cfg"] = np.array([ch, T, k, B, n_class, steps, z_dim], dtype=np.int64)
     st["meta.lr"] = np.array(lr)
+    st["meta.synth"] = np.array(int(synth_big))
     return st
 
 
@@ -479,22 +493,46 @@ def f9_trainer_steps(R):
 
 
 def f10_config1(R):
-    """Config-1 plumbing (frames must be 64x64): T=16, B=2, n_class=1, k=8,
-    3 steps, hinge, reference defaults lr=5e-5 / z_dim=120; ch reduced from 8 to 2 so the
-    committed initial state_dict stays small.  Losses + checksums only."""
-    st = run_trainer(R, adv_loss="hinge", ch=2, T=16, k=8, B=2, n_class=1, steps=3, seed=140,
-                     z_dim=120, lr=5e-5, n_batches=1)   # one batch, re-iterated (trainer.py:216-221)
+    """Config-1 plumbing (frames must be 64x64; BASELINE configs[0]): T=16, B=2, n_class=1, k=8,
+    ch=8, 3 steps, hinge, reference defaults lr=5e-5 / z_dim=120.  The large initial weights and the clips are the
+    closed-form tensors of synth.py (8.5 M generator parameters would not fit a committed fixture).
+    Losses + checksums only."""
+    st = run_trainer(R, adv_loss="hinge", ch=8, T=16, k=8, B=2, n_class=1, steps=3, seed=140,
+                     z_dim=120, lr=5e-5, n_batches=1, synth_big=True)   # one batch, re-iterated (trainer.py:216-221)
     keep = {k: v for k, v in st.items() if not (k.startswith("grad.") or ".sd1." in k)}
     save("f10_config1", keep)
 
 
+F11_NAMES = ("conv.0.cells.1.update_gate.weight", "conv.3.cells.0.reset_gate.weight", "conv.6.cells.2.out_gate.bias",
+             "conv.9.cells.2.out_gate.weight", "conv.9.cells.1.update_gate.bias",
+             "conv.1.conv0.module.weight_bar", "conv.5.conv_sc.module.weight_bar", "conv.11.conv1.module.bias",
+             "conv.1.CBNorm1.embed.weight", "conv.10.CBNorm2.embed.bias", "embedding.weight",
+             "affine_transfrom.weight", "colorize.module.weight_bar",
+             "pre_conv.0.module.weight_bar", "pre_conv.2.module.weight_bar", "pre_skip.module.bias", "attn.gamma",
+             "self_attn.gamma", "attn.value_conv.weight", "self_attn.query_conv.weight", "linear.module.weight_bar",
+             "embed.module.weight_bar", "res3d.conv1.module.weight_bar", "res3d.conv_sc.module.weight_bar",
+             "conv1.conv_sc.module.weight_bar", "conv2.2.conv1.module.weight_bar", "conv.1.conv0.module.weight_bar")
+
+
+def f11_full_width(R):
+    """ONE step of the unmodified reference Trainer at the benchmark's per-clip shape (BASELINE configs[1]: ch=32, T=48,
+    64x64, 101 classes, k=8, hinge, lr 5e-5) with B=2 -- the real 128..1024-channel widths.  Large weights and the clips
+    are synth.py tensors; stored: small state, RNG draws, the six losses, |grad| checksums of EVERY parameter at its
+    optimizer step and the first 8192 elements of the named gradients, post-step SN / BN state."""
+    st = run_trainer(R, adv_loss="hinge", ch=32, T=48, k=8, B=2, n_class=101, steps=1, seed=150,
+                     z_dim=120, lr=5e-5, grads_of=F11_NAMES, synth_big=True, grad_head=8192)
+    keep = {k: v for k, v in st.items() if not (".sd1." in k and v.size >= 4096)}
+    save("f11_full_width", keep)
+
+
 ALL = {"f1": f1_spectral_norm, "f2": f2_conditional_norm, "f3": f3_gresblock, "f4": f4_convgru,
        "f5": f5_attention, "f6": f6_generator, "f7": f7_discriminators, "f8": f8_helpers,
-       "f9": f9_trainer_steps, "f10": f10_config1}
+       "f9": f9_trainer_steps, "f10": f10_config1, "f11": f11_full_width}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
     torch.use_deterministic_algorithms(False)
+    sys.path.insert(0, HERE)
     R = import_reference()
     which = sys.argv[1:] or list(ALL)
     for w in which:

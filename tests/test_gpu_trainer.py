@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import sub
+from conftest import fixture_real, full_states, sub
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -26,8 +26,8 @@ def make_trainer(g, base, adv, dtype):
                              total_epoch=1, d_iters=1, batch_size=B, g_lr=lr, d_lr=lr, beta1=0.0, beta2=0.9,
                              n_class=n_class, k_sample=k)
     tr = Trainer([], cfg, device=torch.device(DEV), compute_dtype=dtype)
-    for net, tag in ((tr.G, "G"), (tr.D_s, "Ds"), (tr.D_t, "Dt")):
-        net.load_state_dict({kk: torch.as_tensor(v) for kk, v in sub(base, tag + ".sd0").items()})
+    for net, sd in zip((tr.G, tr.D_s, tr.D_t), full_states(base)):
+        net.load_state_dict({kk: torch.as_tensor(v) for kk, v in sd.items()})
         net.train()
     return tr, steps
 
@@ -62,12 +62,12 @@ def run(g, base, adv, dtype):
                 orig()
             return stepper
         opt.step = wrap()
-    nb = len([k for k in base if k.startswith("in.real.")])
+    nb = len([k for k in base if k.startswith("in.labels.")])
     out = []
     for s in range(steps):
         draws = {"perm_real": base[f"in.perm_real.{s}"], "z": base[f"in.z.{s}"], "z_class": base[f"in.z_class.{s}"],
                  "perm_fake": base[f"in.perm_fake.{s}"]}
-        losses = tr.train_step(torch.as_tensor(base[f"in.real.{s % nb}"]), torch.as_tensor(base[f"in.labels.{s % nb}"]), draws)
+        losses = tr.train_step(torch.as_tensor(fixture_real(base, s % nb)), torch.as_tensor(base[f"in.labels.{s % nb}"]), draws)
         out.append([float(v.detach()) for v in losses])
         want = g[f"out.losses.{s}"]
         if dtype == torch.float32:

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import sub
+from conftest import fixture_real, full_states, sub
 from oracle import dvdgan_cpu as O
 
 RTOL, ATOL = 1e-5, 1e-6
@@ -204,12 +204,12 @@ def _run_steps(g, inputs, adv, check_named=True):
     ch, T, k, B, n_class, steps, z_dim = [int(v) for v in inputs["meta.cfg"]] if "meta.cfg" in inputs \
         else [int(v) for v in g["meta.cfg"]]
     lr = float(g["meta.lr"])
-    st = O.TrainState(O.make_state(sub(inputs, "G.sd0")), O.make_state(sub(inputs, "Ds.sd0")),
-                      O.make_state(sub(inputs, "Dt.sd0")), ch=ch, n_frames=T, k_sample=k,
+    sds = full_states(inputs)
+    st = O.TrainState(O.make_state(sds[0]), O.make_state(sds[1]), O.make_state(sds[2]), ch=ch, n_frames=T, k_sample=k,
                       n_class=n_class, z_dim=z_dim, adv=adv, g_lr=lr, d_lr=lr)
-    nb = len([k_ for k_ in inputs if k_.startswith("in.real.")])
+    nb = len([k_ for k_ in inputs if k_.startswith("in.labels.")])
     for s in range(steps):
-        losses = O.train_step(st, t(inputs[f"in.real.{s % nb}"]), t(inputs[f"in.labels.{s % nb}"]),
+        losses = O.train_step(st, t(fixture_real(inputs, s % nb)), t(inputs[f"in.labels.{s % nb}"]),
                               t(inputs[f"in.z.{s}"]), t(inputs[f"in.z_class.{s}"]),
                               inputs[f"in.perm_real.{s}"], inputs[f"in.perm_fake.{s}"])
         np.testing.assert_allclose(losses, g[f"out.losses.{s}"], rtol=2e-4, atol=2e-5,
@@ -240,3 +240,25 @@ def test_f9_trainer_wgangp(golden):
 def test_f10_config1_plumbing(golden):
     g = golden("f10_config1")
     _run_steps(g, g, "hinge")
+
+
+# ------------------------------------------------------------------ F11: the benchmark's real channel widths
+def test_f11_full_width_step(golden):
+    """The oracle against ONE step of the real reference at ch=32, T=48, 64x64, 101 classes, k=8, B=2 (BASELINE
+    configs[1] per-clip shape): six losses, |grad| checksum of every parameter of the three networks at its optimizer
+    step, and the stored heads of the named gradients."""
+    g = golden("f11_full_width")
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    sds = full_states(g)
+    st = O.TrainState(O.make_state(sds[0]), O.make_state(sds[1]), O.make_state(sds[2]), ch=ch, n_frames=T, k_sample=k,
+                      n_class=n_class, z_dim=z_dim, adv="hinge", g_lr=float(g["meta.lr"]), d_lr=float(g["meta.lr"]))
+    snaps = O.snapshot_grads(st)
+    losses = O.train_step(st, t(fixture_real(g, 0)), t(g["in.labels.0"]), t(g["in.z.0"]), t(g["in.z_class.0"]),
+                          g["in.perm_real.0"], g["in.perm_fake.0"])
+    np.testing.assert_allclose(losses, g["out.losses.0"], rtol=2e-4, atol=2e-5)
+    for tag in ("Ds", "Dt", "G"):
+        keys = [str(x) for x in g[f"meta.gsum_keys.{tag}"]]
+        got = np.array([float(snaps[tag][kk].double().abs().sum()) for kk in keys])
+        np.testing.assert_allclose(got, g[f"out.gsum.0.{tag}"], rtol=2e-3, err_msg=f"{tag} gradient checksums")
+        for kk, v in sub(g, f"grad.0.{tag}").items():
+            close(snaps[tag][kk].reshape(-1)[:v.size], v, 2e-3, 1e-7, what=f"{tag} grad {kk}")
