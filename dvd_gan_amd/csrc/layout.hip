@@ -93,7 +93,7 @@ extern "C" int dvd_convert(int sdt, const void* src, int ddt, void* dst, long lo
     return launch_status();
 }
 
-extern "C" int dvd_abi_version(void) { return 3; }
+extern "C" int dvd_abi_version(void) { return 4; }
 extern "C" const char* dvd_strerror(int code) {
     switch (code) {
         case DVD_OK: return "ok";

@@ -484,10 +484,15 @@ extern "C" int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames
     return launch_status();
 }
 
-extern "C" int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames,
-                                int P, int C, int ld, const float* mean, const float* rstd, const float* gb,
-                                const int* samp, int B, float* dgb, float* s12, int relu, void* stream) {
-    if (!g || !x || !dx || !mean || !rstd || !gb || !samp || !dgb || !s12 || (relu && !a)) return DVD_E_ARG;
+// Backward of the conditional batch norm in two stages so a data-parallel caller can all-reduce the two per-channel
+// sums between them (cross-replica batch norm, Generator.py:57 TODO / SURVEY section 8e):
+//   reduce: dgb[s][0..C) += sum g*xhat, dgb[s][C..2C) += sum g over the frames conditioned on row s;  s12 = the two
+//           gamma-weighted totals over all condition rows (sum dxhat | sum dxhat*xhat)
+//   apply : dx = rstd * (g*gamma_s - s12[c]/rows_total - xhat * s12[C+c]/rows_total)
+extern "C" int dvd_cbn_backward_reduce(int dtype, const void* g, const void* a, const void* x, long long frames, int P, int C,
+                                       int ld, const float* mean, const float* rstd, const float* gb, const int* samp, int B,
+                                       float* dgb, float* s12, int relu, void* stream) {
+    if (!g || !x || !mean || !rstd || !gb || !samp || !dgb || !s12 || (relu && !a)) return DVD_E_ARG;
     if (frames <= 0 || P <= 0 || B <= 0) return DVD_E_ARG;
     if ((ld & 7) || C > ld || ld / 8 > 256) return DVD_E_SHAPE;
     const int chunk = 2048;
@@ -495,13 +500,30 @@ extern "C" int dvd_cbn_backward(int dtype, const void* g, const void* a, const v
     BY_DTYPE(dtype, cbn_bwd_reduce_kernel<T><<<grid, 256, 0, S_>>>((const T*)g, (const T*)a, (const T*)x, P, C, ld,
                                                                    mean, rstd, samp, dgb, relu, chunk));
     cbn_bwd_sums_kernel<<<cdiv(C, 128), 128, 0, S_>>>(gb, dgb, B, C, s12);
-    const long long rows = frames * P;
-    const float inv_n = (float)(1.0 / (double)rows);
+    return launch_status();
+}
+
+extern "C" int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames,
+                                      int P, int C, int ld, const float* mean, const float* rstd, const float* gb,
+                                      const int* samp, const float* s12, long long rows_total, int relu, void* stream) {
+    if (!g || !x || !dx || !mean || !rstd || !gb || !samp || !s12 || (relu && !a)) return DVD_E_ARG;
+    if (frames <= 0 || P <= 0 || rows_total < frames * P) return DVD_E_ARG;
+    if ((ld & 7) || C > ld || ld / 8 > 256) return DVD_E_SHAPE;
+    const float inv_n = (float)(1.0 / (double)rows_total);
     const int nj = 256 / (ld / 8), chunk2 = nj * 16;
     dim3 grid2((unsigned)frames, cdiv(P, chunk2));
     BY_DTYPE(dtype, cbn_bwd_apply_kernel<T><<<grid2, 256, 0, S_>>>((const T*)g, (const T*)a, (const T*)x, (T*)dx, P, C,
                                                                    ld, mean, rstd, gb, samp, s12, inv_n, relu, chunk2));
     return launch_status();
+}
+
+extern "C" int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames,
+                                int P, int C, int ld, const float* mean, const float* rstd, const float* gb,
+                                const int* samp, int B, float* dgb, float* s12, int relu, void* stream) {
+    if (!dx) return DVD_E_ARG;
+    const int rc = dvd_cbn_backward_reduce(dtype, g, a, x, frames, P, C, ld, mean, rstd, gb, samp, B, dgb, s12, relu, stream);
+    if (rc != DVD_OK) return rc;
+    return dvd_cbn_backward_apply(dtype, g, a, x, dx, frames, P, C, ld, mean, rstd, gb, samp, s12, frames * P, relu, stream);
 }
 
 // y = scale * sum over (pt,2,2) windows; output grid frames x To x Ho x Wo

@@ -114,6 +114,11 @@ class _SNHolder(nn.Module):
         self.module = _SNInner(shape, bias_n, init_weight)
 
 
+def _check_frame_size(H, W):
+    if H < 1 or W < 1 or H & (H - 1) or W & (W - 1):
+        raise ValueError(f"{H}x{W} frames: the HIP convolution kernels need power-of-two frame sizes (64x64, 128x128, ...)")
+
+
 class _DiscBase(nn.Module):
     def _set_train_weights(self, flag):
         for m in self.modules():
@@ -157,6 +162,7 @@ class SpatialDiscriminator(_DiscBase):
 
     def _forward(self, x, class_id):
         B, T, C_, H, W = x.shape
+        _check_frame_size(H, W)
         xc = Fn.ToChannelsLast.apply(x.reshape(B * T, C_, H, W), self.compute_dtype, None)
         c1 = self.pre_conv[0](xc, act=L.ACT_RELU)
         p2 = Fn.Pool.apply(self.pre_conv[2](c1), 1)
@@ -189,6 +195,7 @@ class TemporalDiscriminator(_DiscBase):
             clear_spectral_norm(sn)
 
     def _forward(self, x, class_id):
+        _check_frame_size(x.shape[-2], x.shape[-1])
         xc = Fn.ToChannelsLast.apply(x, self.compute_dtype, None)            # [B,T,h,w,8]
         c1 = self.pre_conv[0](xc, act=L.ACT_RELU)
         p2 = Fn.Pool.apply(self.pre_conv[2](c1), 2)

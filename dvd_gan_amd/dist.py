@@ -4,9 +4,15 @@ The reference only has nn.DataParallel (trainer.py:353-359): single process, gra
 onto GPU 0, batch-norm statistics and SN power iterations per replica.  Here each rank owns
 clips [r*B/N, (r+1)*B/N) of the global batch; after each of the three backward passes the flat
 gradient buffer of that network (optim.FlatAdam.grad) is all-reduced on a side stream: D_s in one piece
-(it overlaps the D_t forward/backward), the generator's in buckets that start as soon as the backward
-pass has left the corresponding ConvGRU stage (the buffer's tail is final first).  Batch-norm statistics stay per replica (= DataParallel
-semantics); SN u/v need no exchange because weights are identical on every rank.
+(it overlaps the D_t forward/backward), D_t's overlaps the generator step's D_s forward, the generator's goes in
+buckets that start as soon as the backward pass has left the corresponding ConvGRU stage (the buffer's tail is final
+first).  SN u/v need no exchange because weights are identical on every rank (`broadcast_state` makes them so).
+
+Two batch-norm semantics (Trainer(dp_mode=...)):
+  "replica"  per-replica statistics and per-replica condition rows -- what nn.DataParallel does (default);
+  "global"   cross-replica conditional batch norm (the reference's own TODO, Generator.py:57) plus the condition
+             matrix gathered over the ranks, so that N ranks reproduce ONE process on the global batch exactly
+             (including the reference's condition mis-ordering, which indexes the GLOBAL batch).
 """
 import os
 
@@ -25,6 +31,8 @@ def init_from_env(backend=None):
     if use_cuda:
         if os.environ.get("DVD_SHARE_GPU0"):          # test aid: several ranks on one GPU (gloo backend)
             local = 0
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
         torch.cuda.set_device(local)
     backend = backend or os.environ.get("DVD_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
@@ -34,57 +42,115 @@ def init_from_env(backend=None):
     return rank, world, (torch.device("cuda", local) if use_cuda else torch.device("cpu"))
 
 
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def _avg_(t):
+    """In-place mean over the ranks.  RCCL averages inside the collective (ReduceOp.AVG: no extra pass over the
+    buffer); gloo has no AVG, so the CPU / test path divides afterwards."""
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(t)
+        t.div_(dist.get_world_size())
+
+
+def all_reduce_sum_(t):
+    """In-place sum over the ranks on the current stream (cross-replica batch-norm sums: [2C] fp64 / fp32)."""
+    dist.all_reduce(t)
+    return t
+
+
 class GradExchange:
     """Averages flat gradient buffers across ranks; asynchronous on a side stream when on GPU."""
 
     def __init__(self):
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.world = world_size()
         self.stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
         self.pending = {}
 
-    def start(self, key, flat_grad):
-        """Begin averaging `flat_grad` (in place).  Call finish(key) before the buffer is read."""
-        if self.world == 1:
-            return
+    def _launch(self, key, view):
         if self.stream is None:                       # CPU / gloo: synchronous
-            dist.all_reduce(flat_grad)
-            flat_grad.div_(self.world)
+            _avg_(view)
             return
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            dist.all_reduce(flat_grad)
-            flat_grad.div_(self.world)
+            _avg_(view)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        self.pending[key] = ev
+        self.pending.setdefault(key, []).append(ev)
+
+    def start(self, key, flat_grad):
+        """Begin averaging `flat_grad` (in place).  Call finish(key) before the buffer is read."""
+        if self.world > 1:
+            self._launch(key, flat_grad)
 
     def start_range(self, key, flat_grad, lo, hi):
         """Begin averaging flat_grad[lo:hi] (a bucket); several ranges may be pending under one key.  Every rank must
         issue the same ranges in the same order."""
-        if self.world == 1 or hi <= lo:
-            return
-        view = flat_grad[lo:hi]
-        if self.stream is None:
-            dist.all_reduce(view)
-            view.div_(self.world)
-            return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            dist.all_reduce(view)
-            view.div_(self.world)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self.pending.setdefault(key, [])
-        if not isinstance(self.pending[key], list):
-            self.pending[key] = [self.pending[key]]
-        self.pending[key].append(ev)
+        if self.world > 1 and hi > lo:
+            self._launch(key, flat_grad[lo:hi])
 
     def finish(self, key):
-        ev = self.pending.pop(key, None)
-        if ev is None:
-            return
-        for e in (ev if isinstance(ev, list) else [ev]):
+        for e in self.pending.pop(key, ()):
             torch.cuda.current_stream().wait_event(e)
+
+
+def broadcast_state(nets, flats=()):
+    """Make every rank start from rank 0's model: the flat parameter buffers (`flats`), every parameter that is not
+    a view of one of them (SN u / v are requires_grad=False parameters) and all buffers (batch-norm statistics).
+    Without this, ranks seeded differently (needed for distinct z per rank) would average gradients of DIFFERENT
+    models and never agree -- the reference's nn.DataParallel replicates from GPU 0 every forward instead."""
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for f in flats:
+            dist.broadcast(f, 0)
+        lo_hi = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats]
+        for net in nets:
+            for t in list(net.parameters()) + list(net.buffers()):
+                if any(lo <= t.data_ptr() < hi for lo, hi in lo_hi):
+                    continue
+                if t.dim() == 0:                      # gloo cannot broadcast 0-d integer tensors in place on every build
+                    v = t.reshape(1).clone()
+                    dist.broadcast(v, 0)
+                    t.copy_(v[0])
+                else:
+                    dist.broadcast(t, 0)
+
+
+def shared_seed():
+    """One random 63-bit seed agreed by all ranks (drawn on rank 0): seeds the frame-id generator, so every rank samples
+    the same k frame ids per step while z / labels stay per rank."""
+    seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+    if world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        s = seed.to(dev)
+        dist.broadcast(s, 0)
+        seed = s.cpu()
+    return int(seed)
+
+
+class AllGatherRows(torch.autograd.Function):
+    """[b, ...] per rank -> [world * b, ...] (rank-major), differentiable: the gradient of a rank's rows is the SUM over
+    the ranks of the gradients they hold for those rows."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        out = x.new_empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x) if dist.get_backend() == "nccl" else \
+            dist.all_gather(list(out.chunk(dist.get_world_size())), x)
+        ctx.b = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g)
+        r = dist.get_rank()
+        return g[r * ctx.b:(r + 1) * ctx.b]
 
 
 def shard(t, rank, world):

@@ -140,11 +140,13 @@ class CondBatchNorm(Function):
     """y = relu?(gb[s][:C] * bn(x) + gb[s][C:]),  s = samp[frame]     Normalization.py:78-88"""
 
     @staticmethod
-    def forward(ctx, x, gb, samp, C_real, relu, training, run_mean, run_var, eps, momentum):
-        mean, rstd = K.bn_stats(x, C_real, training, eps, momentum, run_mean, run_var)
+    def forward(ctx, x, gb, samp, C_real, relu, training, run_mean, run_var, eps, momentum, replicas=None):
+        """replicas: None (per-replica statistics = nn.DataParallel, trainer.py:357) or (world, all_reduce_sum_) for
+        cross-replica batch norm (Generator.py:57 TODO): statistics and their backward sums span the global batch."""
+        mean, rstd = K.bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas if training else None)
         y = K.cbn_apply(x, C_real, mean, rstd, gb, samp, relu)
         ctx.save_for_backward(x, y, gb, samp, mean, rstd)
-        ctx.C_real, ctx.relu, ctx.training = C_real, relu, training
+        ctx.C_real, ctx.relu, ctx.training, ctx.replicas = C_real, relu, training, replicas
         return y
 
     @staticmethod
@@ -152,8 +154,8 @@ class CondBatchNorm(Function):
         x, y, gb, samp, mean, rstd = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError("CondBatchNorm backward is implemented for training mode only")
-        dx, dgb = K.cbn_backward(g.contiguous(), y, x, ctx.C_real, mean, rstd, gb, samp, ctx.relu)
-        return dx, dgb, None, None, None, None, None, None, None, None
+        dx, dgb = K.cbn_backward(g.contiguous(), y, x, ctx.C_real, mean, rstd, gb, samp, ctx.relu, ctx.replicas)
+        return dx, dgb, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------ ConvGRU layer
@@ -221,6 +223,10 @@ class ConvGRULayer(Function):
         d.h_all, d.u_all, d.r_all = h_all.data_ptr(), u_all.data_ptr(), r_all.data_ptr()
         d.o_all, d.hr_all = o_all.data_ptr(), hr_all.data_ptr()
         d.ws, d.dh_out, d.dg, d.carry = ws.data_ptr(), dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
+        dh0_32 = None
+        if h0 is not None and ctx.needs_input_grad[9]:          # gradient wrt the supplied initial state (ConvGRU.py:104)
+            dh0_32 = torch.empty(M, hid, dtype=torch.float32, device=dev)
+            d.dh0 = dh0_32.data_ptr()
         L.check(L.lib().dvd_convgru_layer_backward(C.byref(d), L.stream()))
         # ---- everything below is batched over all T steps ----
         dgx = K.sum_leading(dg.view(T, -1)).view(B, S1, S2, 3 * hid) if shared_x else dg
@@ -235,7 +241,9 @@ class ConvGRULayer(Function):
             K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot,
                          dbias=db3[g * hid:(g + 1) * hid])
             if h0 is not None:
-                raise RuntimeError("gradient through a supplied initial hidden state is not implemented")
+                # step 0 read the supplied state: h0 (update / reset) or h0 * r_0 = hr_all[0] (out gate)
+                K.conv_wgrad(h0 if g < 2 else hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin,
+                             dw_ci_tot=ctot, frames=B, x_row0=0, dy_row0=0)
             if T > 1:
                 # h-part: steps 1..T-1 read h_{t-1} (update/reset) or h_{t-1}*r_t (out gate)
                 if g < 2:
@@ -245,8 +253,11 @@ class ConvGRULayer(Function):
                     K.conv_wgrad(hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
                                  frames=(T - 1) * B, x_row0=B, dy_row0=B)
             grads.append(dw)
+        dh0 = None
+        if dh0_32 is not None:
+            dh0 = dh0_32.view(h0.shape) if h0.dtype == torch.float32 else K.convert(dh0_32, h0.dtype).view(h0.shape)
         return (dx, grads[0], db3[:hid].clone(), grads[1], db3[hid:2 * hid].clone(), grads[2], db3[2 * hid:].clone(),
-                None, None, None)
+                None, None, dh0)
 
 
 # ------------------------------------------------------------------ attention / head / loss

@@ -11,6 +11,7 @@ Module/ConvGRU.py and Module/GResBlock.py, but organised for the hardware:
 import torch
 import torch.nn as nn
 
+from . import dist as D
 from . import functional as Fn
 from . import kern as K
 from . import lib as L
@@ -90,6 +91,9 @@ class Generator(nn.Module):
         super().__init__()
         if hierar_flag:
             raise NotImplementedError("hierar_flag=True is broken in the reference (Generator.py:66,109)")
+        if latent_dim < 1 or latent_dim & (latent_dim - 1):
+            raise ValueError(f"latent_dim={latent_dim}: the HIP convolution kernels index frames with shifts, so every "
+                             "stage size (latent_dim * 2^k) must be a power of two (4 -> 64x64, 8 -> 128x128 clips)")
         self.in_dim, self.latent_dim, self.n_class, self.ch, self.n_frames = in_dim, latent_dim, n_class, ch, n_frames
         self.hierar_flag = hierar_flag
         self.compute_dtype = compute_dtype
@@ -108,18 +112,23 @@ class Generator(nn.Module):
             GResBlock(c4, c4, nc, 1), GResBlock(c4, c2, nc),
         ])
         self.colorize = SpectralNormConv(c2, 3, (3, 3))
+        self.dp_global = False                      # data-parallel "global" mode: conditions gathered over the ranks
         self.dp_hooks = False                       # data-parallel trainer sets it: stage-boundary gradient hooks
         self.grad_ready_hook = None                 # callable(first finished module index), armed around backward
         self.grad_ready_stages = (2, 5, 8)          # after each [ConvGRU, GResBlock, GResBlock] group but the last
 
-    def forward(self, x, class_id):
+    def forward(self, x, class_id, hidden=None):
+        """hidden (frame-conditional variant, BASELINE configs[4]): initial ConvGRU states carried in from a conditioning
+        encoder -- one entry per ConvGRU of the stack (4), each None or a list of that ConvGRU's per-layer states
+        [B, hidden_l, S, S] fp32 (None entries = zeros).  They take the place of the `hidden=None` the reference passes at
+        the first frame (Generator.py:91,96 -> ConvGRU.forward(x, hidden), ConvGRU.py:104-118) and receive gradients."""
         sn = prefetch_spectral_norm(self, self.compute_dtype)    # SN + weight packing of all layers on the side stream
         try:
-            return self._forward(x, class_id)
+            return self._forward(x, class_id, hidden)
         finally:
             clear_spectral_norm(sn)
 
-    def _forward(self, x, class_id):
+    def _forward(self, x, class_id, hidden=None):
         B, T = x.shape[0], self.n_frames
         dev = x.device
         class_emb = Fn.Embedding.apply(self.embedding.weight, class_id.to(torch.int32))
@@ -131,11 +140,25 @@ class Generator(nn.Module):
         t_idx = torch.arange(T, device=dev).view(T, 1)
         b_idx = torch.arange(B, device=dev).view(1, B)
         samp = ((b_idx * T + t_idx) % B).reshape(-1).to(torch.int32)
+        cond = zc
+        if self.dp_global and D.world_size() > 1:
+            # one process on the global batch would condition frame (b, t) on row (b*T + t) mod B_global: gather the
+            # condition rows of all ranks (rank-major = global batch order) and index them with the GLOBAL b
+            cond = D.AllGatherRows.apply(zc)
+            b_glob = torch.distributed.get_rank() * B + b_idx
+            samp = ((b_glob * T + t_idx) % cond.shape[0]).reshape(-1).to(torch.int32)
+        n_gru = 0
         for k, m in enumerate(self.conv):
             if isinstance(m, ConvGRU):
-                y = m.run(y, T, shared_x=(k == 0))[-1]
+                h0 = hidden[n_gru] if hidden is not None else None
+                n_gru += 1
+                if h0 is not None:
+                    if len(h0) != m.n_layers:
+                        raise ValueError("`hidden` needs one state (or None) per ConvGRU layer")
+                    h0 = [None if h is None else Fn.ToChannelsLast.apply(h, self.compute_dtype, None) for h in h0]
+                y = m.run(y, T, shared_x=(k == 0), hidden=h0)[-1]
             else:
-                y = m.run(y, zc, samp)
+                y = m.run(y, cond, samp)
             if self.dp_hooks and y.requires_grad and k in self.grad_ready_stages:
                 # fires when the backward pass has produced d/dy: every module after k has all its gradients queued
                 y.register_hook(lambda g_, k_=k: self.grad_ready_hook(k_ + 1) if self.grad_ready_hook else None)

@@ -177,8 +177,10 @@ def _f(v):
     return C.c_float(float(v))
 
 
-def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var):
-    """-> (mean, rstd) fp32 [C_real]; updates the running buffers in training mode."""
+def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas=None):
+    """-> (mean, rstd) fp32 [C_real]; updates the running buffers in training mode.
+    replicas: None, or (world, all_reduce_sum_) for cross-replica statistics -- the [2C] fp64 sums are added over the
+    replicas before mean / variance are formed from world * rows samples."""
     ld = x.shape[-1]
     rows = x.numel() // ld
     mean = torch.empty(C_real, dtype=torch.float32, device=x.device)
@@ -187,6 +189,9 @@ def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var):
     if training:
         sums = torch.zeros(2 * C_real, dtype=torch.float64, device=x.device)
         L.check(L.lib().dvd_bn_stats(L.dt(x), L.ptr(x), _ll(rows), C_real, ld, L.ptr(sums), L.stream()))
+        if replicas is not None:
+            replicas[1](sums)
+            rows *= replicas[0]
     L.check(L.lib().dvd_bn_finalize(L.ptr(sums), _ll(rows), C_real, _f(eps), _f(momentum), int(training),
                                     L.ptr(mean), L.ptr(rstd), L.ptr(run_mean), L.ptr(run_var), L.stream()))
     return mean, rstd
@@ -201,17 +206,27 @@ def cbn_apply(x, C_real, mean, rstd, gb, samp, relu):
     return y
 
 
-def cbn_backward(g, a, x, C_real, mean, rstd, gb, samp, relu):
-    """-> (dx, dgb[B][2C])"""
+def cbn_backward(g, a, x, C_real, mean, rstd, gb, samp, relu, replicas=None):
+    """-> (dx, dgb[B][2C]).  replicas: as in bn_stats -- the two per-channel sums of the batch-norm backward are added
+    over the replicas between the reduce and the apply stage."""
     dx = torch.empty_like(x)
     frames = x.shape[0]
     P = x.numel() // (frames * x.shape[-1])
     B = gb.shape[0]
     dgb = torch.zeros_like(gb)
     s12 = torch.empty(2 * C_real, dtype=torch.float32, device=x.device)
-    L.check(L.lib().dvd_cbn_backward(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
-                                     x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb),
-                                     L.ptr(s12), int(relu), L.stream()))
+    if replicas is None:
+        L.check(L.lib().dvd_cbn_backward(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
+                                         x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb),
+                                         L.ptr(s12), int(relu), L.stream()))
+        return dx, dgb
+    L.check(L.lib().dvd_cbn_backward_reduce(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), _ll(frames), P, C_real, x.shape[-1],
+                                            L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb), L.ptr(s12),
+                                            int(relu), L.stream()))
+    replicas[1](s12)
+    L.check(L.lib().dvd_cbn_backward_apply(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
+                                           x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), L.ptr(s12),
+                                           _ll(frames * P * replicas[0]), int(relu), L.stream()))
     return dx, dgb
 
 

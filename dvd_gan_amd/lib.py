@@ -46,7 +46,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def check(code):

@@ -174,6 +174,7 @@ class ConditionalNorm(nn.Module):
         w[:, in_channel:].zero_()
         self.embed.weight = nn.Parameter(w)
         self.embed.bias = nn.Parameter(b)
+        self.replicas = None               # (world, all_reduce_sum_) when batch statistics span all replicas
 
     def forward(self, x, cond, samp, relu=True):
         """x: channels-last [frames, H, W, Cp]; cond: fp32 [B, n_condition]; samp: int32 [frames]."""
@@ -181,4 +182,4 @@ class ConditionalNorm(nn.Module):
         if self.training:
             self.bn.num_batches_tracked += 1
         return Fn.CondBatchNorm.apply(x, gb, samp, self.in_channel, relu, self.training, self.bn.running_mean,
-                                      self.bn.running_var, 1e-5, 0.1)
+                                      self.bn.running_var, 1e-5, 0.1, self.replicas)

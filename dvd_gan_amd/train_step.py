@@ -16,6 +16,7 @@ import time
 import torch
 
 from . import functional as Fn
+from . import dist as D
 from .dist import GradExchange
 from .disc_nets import SpatialDiscriminator, TemporalDiscriminator
 from .gen_net import Generator
@@ -29,7 +30,7 @@ class _StepLR:
     def __init__(self, opt, kind, base_lr):
         self.opt, self.kind, self.base, self.n = opt, kind, base_lr, 0
 
-    def step(self):
+    def step(self, metric=None):
         self.n += 1
         n, lr = self.n, self.base
         if self.kind == "step":
@@ -44,8 +45,47 @@ class _StepLR:
         return [self.opt.param_groups[0]["lr"]]
 
 
+class _PlateauLR:
+    """lr_schr='reduce' (trainer.py:158-176): ReduceLROnPlateau(mode='min', factor=lr_decay, patience=100,
+    threshold=1e-4 'rel', cooldown=0, min_lr=1e-10, eps=1e-8) -- same arithmetic as torch's scheduler.  The reference
+    calls `.step()` WITHOUT the metric (trainer.py:254,270,308), which raises TypeError at its first iteration, so that
+    mode never ran there; here each network's scheduler is fed that network's loss of the step (what the configuration
+    evidently intends).  Reading the loss costs one host sync per optimizer phase -- only in this mode."""
+
+    def __init__(self, opt, factor, base_lr, patience=100, threshold=1e-4, min_lr=1e-10, eps=1e-8):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        self.opt, self.factor, self.patience, self.threshold, self.min_lr, self.eps = opt, factor, patience, threshold, min_lr, eps
+        self.best, self.bad = float("inf"), 0
+        self.opt.param_groups[0]["lr"] = base_lr
+
+    def step(self, metric):
+        if metric is None:
+            raise TypeError("step() missing 1 required positional argument: 'metrics'")
+        m = float(metric)
+        if m < self.best * (1.0 - self.threshold):
+            self.best, self.bad = m, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            old = self.opt.param_groups[0]["lr"]
+            new = max(old * self.factor, self.min_lr)
+            if old - new > self.eps:
+                self.opt.param_groups[0]["lr"] = new
+            self.bad = 0
+
+    def get_lr(self):
+        return [self.opt.param_groups[0]["lr"]]
+
+
 class Trainer(object):
-    def __init__(self, data_loader, config, device=None, compute_dtype=torch.bfloat16, latent_dim=4):
+    def __init__(self, data_loader, config, device=None, compute_dtype=torch.bfloat16, latent_dim=4, dp_mode="replica"):
+        """dp_mode (data-parallel runs only): "replica" = per-replica batch-norm statistics and condition rows, the
+        semantics of the reference's nn.DataParallel (trainer.py:353-359); "global" = cross-replica conditional batch
+        norm + gathered conditions: N ranks reproduce one process on the global batch."""
+        if dp_mode not in ("replica", "global"):
+            raise ValueError("dp_mode must be 'replica' or 'global'")
+        self.dp_mode = dp_mode
         self.data_loader = data_loader
         c = config
         self.adv_loss, self.z_dim = c.adv_loss, c.z_dim
@@ -54,6 +94,7 @@ class Trainer(object):
         self.total_epoch, self.d_iters, self.batch_size = c.total_epoch, c.d_iters, c.batch_size
         self.g_lr, self.d_lr, self.beta1, self.beta2 = c.g_lr, c.d_lr, c.beta1, c.beta2
         self.n_class, self.k_sample = c.n_class, c.k_sample
+        self.lr_decay = getattr(c, "lr_decay", 0.9999)
         self.pretrained_model = getattr(c, "pretrained_model", None)
         self.model_save_path = os.path.join(getattr(c, "model_save_path", "./models"), getattr(c, "version", ""))
         self.model_save_epoch = getattr(c, "model_save_epoch", 0)
@@ -61,9 +102,14 @@ class Trainer(object):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.compute_dtype, self.latent_dim = compute_dtype, latent_dim
         self.exchange = GradExchange()
+        self.rank = torch.distributed.get_rank() if self.exchange.world > 1 else 0
         self.build_model()
         if self.pretrained_model:
             self.load_pretrained_model()
+        # data parallel: every rank continues from rank 0's model (parameters, SN u / v, BN statistics); frame ids come
+        # from a generator all ranks seed alike, z / labels from each rank's own default generator
+        self._sync_replicas()
+        self.frame_gen = torch.Generator().manual_seed(D.shared_seed()) if self.exchange.world > 1 else None
 
     # ---- trainer.py:345-366
     def build_model(self):
@@ -71,7 +117,17 @@ class Trainer(object):
         self.G = Generator(self.z_dim, self.latent_dim, self.n_class, self.g_chn, self.n_frames, compute_dtype=dt).to(self.device)
         self.D_s = SpatialDiscriminator(self.ds_chn, self.n_class, compute_dtype=dt).to(self.device)
         self.D_t = TemporalDiscriminator(self.dt_chn, self.n_class, compute_dtype=dt).to(self.device)
+        if self.exchange.world > 1 and self.dp_mode == "global":
+            from .sn_layers import ConditionalNorm
+            self.G.dp_global = True
+            for m in self.G.modules():
+                if isinstance(m, ConditionalNorm):
+                    m.replicas = (self.exchange.world, D.all_reduce_sum_)
         self.select_opt_schr()
+
+    def _sync_replicas(self):
+        D.broadcast_state((self.G, self.D_s, self.D_t),
+                          (self.g_optimizer.flat, self.ds_optimizer.flat, self.dt_optimizer.flat))
 
     # ---- trainer.py:134-176
     def select_opt_schr(self):
@@ -88,11 +144,15 @@ class Trainer(object):
             off += prm.numel()
         self.ds_optimizer = FlatAdam(self.D_s.parameters(), self.d_lr, betas)
         self.dt_optimizer = FlatAdam(self.D_t.parameters(), self.d_lr, betas)
-        if self.lr_schr not in ("const", "step", "exp", "multi"):
-            raise NotImplementedError("lr_schr='reduce' (ReduceLROnPlateau) is not ported")
-        self.g_lr_scher = _StepLR(self.g_optimizer, self.lr_schr, self.g_lr)
-        self.ds_lr_scher = _StepLR(self.ds_optimizer, self.lr_schr, self.d_lr)
-        self.dt_lr_scher = _StepLR(self.dt_optimizer, self.lr_schr, self.d_lr)
+        if self.lr_schr in ("const", "step", "exp", "multi"):
+            self.g_lr_scher = _StepLR(self.g_optimizer, self.lr_schr, self.g_lr)
+            self.ds_lr_scher = _StepLR(self.ds_optimizer, self.lr_schr, self.d_lr)
+            self.dt_lr_scher = _StepLR(self.dt_optimizer, self.lr_schr, self.d_lr)
+        else:                                   # trainer.py:158-176: anything else selects ReduceLROnPlateau
+            self.g_lr_scher = _PlateauLR(self.g_optimizer, self.lr_decay, self.g_lr)
+            self.ds_lr_scher = _PlateauLR(self.ds_optimizer, self.lr_decay, self.d_lr)
+            self.dt_lr_scher = _PlateauLR(self.dt_optimizer, self.lr_decay, self.d_lr)
+        self._plateau = not isinstance(self.g_lr_scher, _StepLR)
 
     # ---- trainer.py:114-121
     def calc_loss(self, x, real_flag):
@@ -113,22 +173,31 @@ class Trainer(object):
         self.D_t._set_train_weights(not flag)
 
     # ---- trainer.py:223-307, one iteration (d_iters D updates + one G update)
-    def train_step(self, real_videos, real_labels, draws=None):
+    def _check_labels(self, labels):
+        """Class ids index embedding tables on the device (no bounds check there): reject a label outside
+        [0, n_class) while it is still on the host, like the IndexError nn.Embedding raises in the reference."""
+        if not labels.is_cuda and labels.numel() and (int(labels.min()) < 0 or int(labels.max()) >= self.n_class):
+            raise IndexError(f"class id out of range for n_class={self.n_class}: [{int(labels.min())}, {int(labels.max())}]")
+        return labels
+
+    def train_step(self, real_videos, real_labels, draws=None, hidden=None):
         """real_videos [B,3,T,H,W], real_labels [B].  `draws` (tests): dict with the reference's RNG
-        draws perm_real / z / z_class / perm_fake.  Returns the six loss terms as device scalars:
+        draws perm_real / z / z_class / perm_fake.  `hidden`: initial ConvGRU states for the generator
+        (Generator.forward, frame-conditional variant).  Returns the six loss terms as device scalars:
         ds_real, ds_fake, dt_real, dt_fake, g_s, g_t."""
         real_videos = real_videos.to(self.device).permute(0, 2, 1, 3, 4).contiguous()
-        real_labels = real_labels.to(self.device)
+        real_labels = self._check_labels(real_labels).to(self.device)
         T, k = self.n_frames, self.k_sample
         ex = self.exchange
+        fg = self.frame_gen
         for _ in range(self.d_iters):
-            ids_real = draw_frame_ids(T, k) if draws is None else torch.as_tensor(draws["perm_real"])[:k].sort()[0]
+            ids_real = draw_frame_ids(T, k, fg) if draws is None else torch.as_tensor(draws["perm_real"])[:k].sort()[0]
             real_s = sample_k_frames(real_videos, T, k, ids_real)
             z = (torch.randn(self.batch_size, self.z_dim) if draws is None else torch.as_tensor(draws["z"])).to(self.device)
-            z_class = self.label_sample() if draws is None else torch.as_tensor(draws["z_class"]).to(self.device)
+            z_class = self.label_sample() if draws is None else self._check_labels(torch.as_tensor(draws["z_class"])).to(self.device)
             ex.finish("G")
-            fake_videos = self.G(z, z_class)
-            ids_fake = draw_frame_ids(T, k) if draws is None else torch.as_tensor(draws["perm_fake"])[:k].sort()[0]
+            fake_videos = self.G(z, z_class, hidden)
+            ids_fake = draw_frame_ids(T, k, fg) if draws is None else torch.as_tensor(draws["perm_fake"])[:k].sort()[0]
             fake_s = sample_k_frames(fake_videos, T, k, ids_fake)
             # ---------------- D_s
             ds_loss_real = self.calc_loss(self.D_s(real_s, real_labels), True)
@@ -142,16 +211,22 @@ class Trainer(object):
             dt_loss_fake = self.calc_loss(self.D_t(fake_d.detach(), z_class), False)
             ex.finish("Ds")
             self.ds_optimizer.step()
-            self.ds_lr_scher.step()
+            self.ds_lr_scher.step((ds_loss_real + ds_loss_fake) if self._plateau else None)
             self.dt_optimizer.zero_grad()
             (dt_loss_real + dt_loss_fake).backward()
             ex.start("Dt", self.dt_optimizer.grad)
-            ex.finish("Dt")
-            self.dt_optimizer.step()
-            self.dt_lr_scher.step()
-        # ---------------- G, through the updated discriminators, weights of D held constant
+            last = _ == self.d_iters - 1
+            if not last:
+                ex.finish("Dt")
+                self.dt_optimizer.step()
+                self.dt_lr_scher.step((dt_loss_real + dt_loss_fake) if self._plateau else None)
+        # ---------------- G, through the updated discriminators, weights of D held constant.  The D_t gradient exchange
+        # of the last D iteration overlaps the D_s forward (D_s is already updated; D_t's update waits for the exchange)
         self._freeze_d(True)
         g_s_loss = self.calc_loss(self.D_s(fake_s, z_class), True)
+        ex.finish("Dt")
+        self.dt_optimizer.step()
+        self.dt_lr_scher.step((dt_loss_real + dt_loss_fake) if self._plateau else None)
         g_t_loss = self.calc_loss(self.D_t(fake_d, z_class), True)
         self._freeze_d(False)
         self.g_optimizer.zero_grad()
@@ -170,7 +245,7 @@ class Trainer(object):
             ex.start_range("G", self.g_optimizer.grad, 0, self._g_hi)
         ex.finish("G")
         self.g_optimizer.step()
-        self.g_lr_scher.step()
+        self.g_lr_scher.step((g_s_loss + g_t_loss) if self._plateau else None)
         return ds_loss_real, ds_loss_fake, dt_loss_real, dt_loss_fake, g_s_loss, g_t_loss
 
     # ---- trainer.py:189-343 (loop; logging reduced to a print, no sampling)
@@ -209,10 +284,15 @@ class Trainer(object):
 
     # ---- trainer.py:337-343 / 375-382: reference-compatible checkpoints
     def save_models(self, step):
-        os.makedirs(self.model_save_path, exist_ok=True)
-        for net, tag in ((self.G, "G"), (self.D_s, "Ds"), (self.D_t, "Dt")):
-            torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()},
-                       os.path.join(self.model_save_path, "{}_{}.pth".format(step, tag)))
+        """Rank 0 writes (its batch-norm running statistics are the ones saved in "replica" mode); the others wait."""
+        world = D.world_size()
+        if world == 1 or torch.distributed.get_rank() == 0:
+            os.makedirs(self.model_save_path, exist_ok=True)
+            for net, tag in ((self.G, "G"), (self.D_s, "Ds"), (self.D_t, "Dt")):
+                torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()},
+                           os.path.join(self.model_save_path, "{}_{}.pth".format(step, tag)))
+        if world > 1:
+            torch.distributed.barrier()
 
     def load_pretrained_model(self):
         for net, tag in ((self.G, "G"), (self.D_s, "Ds"), (self.D_t, "Dt")):

@@ -176,6 +176,16 @@ int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames, int P, in
 int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames, int P,
                      int C, int ld, const float* mean, const float* rstd, const float* gb, const int* samp, int B,
                      float* dgb, float* s12, int relu, void* stream);
+/* The same in two stages, for cross-replica batch norm (the reference leaves it as a TODO, Generator.py:57; autograd of
+ * F.batch_norm over a global batch): `reduce` accumulates dgb and writes the two per-channel sums s12[2C]; the caller
+ * all-reduces s12 over the replicas; `apply` produces dx with rows_total = frames * P summed over the replicas.
+ * dvd_cbn_backward == reduce + apply with rows_total = frames * P. */
+int dvd_cbn_backward_reduce(int dtype, const void* g, const void* a, const void* x, long long frames, int P, int C, int ld,
+                            const float* mean, const float* rstd, const float* gb, const int* samp, int B, float* dgb,
+                            float* s12, int relu, void* stream);
+int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames, int P, int C,
+                           int ld, const float* mean, const float* rstd, const float* gb, const int* samp, const float* s12,
+                           long long rows_total, int relu, void* stream);
 
 /* avg / sum pooling over (pt,2,2) windows and its transpose (nearest replication), channels-last.
  * F.avg_pool2d / F.avg_pool3d at Discriminators.py:197,206,225,249,352,361,380,408 and the

@@ -148,11 +148,13 @@ def gresblock(sd, pfx, x, cond, upsample, training=True):
 GEN_STACK = ("gru", "res1", "res2") * 4      # Generator.py:38-55: [ConvGRU, GResBlock, GResBlock(up)] x 4
 
 
-def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True, taps=None):
+def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True, taps=None, hidden=None):
     """Generator.forward, Generator.py:63-120 (hierar_flag=False).
     taps (test aid): a list that receives the input of the first module followed by the output of each of the 12
     modules of `self.conv` ([B*T, C, S, S], b-major frames), each with retain_grad() so a later backward leaves the
-    gradient flowing through that point on the tensor."""
+    gradient flowing through that point on the tensor.
+    hidden (frame-conditional variant): per ConvGRU of the stack (4 entries), None or the list of per-layer states that
+    replaces the `hidden=None` of the first frame (Generator.py:91,96 -> ConvGRU.forward(x, hidden), ConvGRU.py:104-118)."""
     B, T = z.shape[0], n_frames
     class_emb = F.embedding(class_id, sd["embedding.weight"])
     zc = torch.cat([z, class_emb], 1)
@@ -171,10 +173,10 @@ def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True, taps=N
         if kind == "gru":
             if k > 0:
                 y = y.view(B, T, *y.shape[1:])
-            hidden, frames = None, []
+            state, frames = (hidden[k // 3] if hidden is not None else None), []
             for t in range(T):
-                hidden = convgru(sd, pfx, y if k == 0 else y[:, t], hidden)
-                frames.append(hidden[-1])
+                state = convgru(sd, pfx, y if k == 0 else y[:, t], state)
+                frames.append(state[-1])
             y = torch.stack(frames, 1).reshape(B * T, *frames[0].shape[1:])    # b-major frames
         else:
             y = gresblock(sd, pfx, y, cond, 1 if kind == "res1" else 2, training)

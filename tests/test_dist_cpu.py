@@ -51,6 +51,34 @@ def _worker(rank, world, port, out):
         ex.start_range("G", bucketed, lo, hi)
     ex.finish("G")
     assert torch.equal(bucketed, flat)
+    # --- rank-0 broadcast of a model whose ranks were seeded differently (flat buffer + SN-style frozen parameter + buffers)
+    torch.manual_seed(10 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.BatchNorm1d(4))
+    net[0].register_parameter("weight_u", torch.nn.Parameter(torch.randn(4), requires_grad=False))
+    net[1].running_mean.normal_()
+    flat_p = torch.cat([p.data.reshape(-1) for p in net.parameters() if p.requires_grad])
+    off = 0
+    for p in net.parameters():
+        if p.requires_grad:
+            p.data = flat_p[off:off + p.numel()].view(p.shape); off += p.numel()
+    D.broadcast_state([net], [flat_p])
+    state = torch.cat([v.reshape(-1).float() for v in net.state_dict().values()])
+    both = [torch.empty_like(state) for _ in range(world)]
+    torch.distributed.all_gather(both, state)
+    assert torch.equal(both[0], both[1])
+    seed = D.shared_seed()
+    seeds = [None] * world
+    torch.distributed.all_gather_object(seeds, seed)
+    assert seeds[0] == seeds[1]
+    # --- differentiable row gather: forward = concatenation in rank order, backward = sum over ranks of the row gradients
+    xr = (torch.arange(6.).view(2, 3) + 10 * rank).requires_grad_(True)
+    allr = D.AllGatherRows.apply(xr)
+    assert torch.equal(allr.detach(), torch.cat([torch.arange(6.).view(2, 3), torch.arange(6.).view(2, 3) + 10]))
+    (allr * (rank + 1) * torch.arange(1., 5.).view(4, 1)).sum().backward()
+    want = (1 + 2) * torch.arange(1., 5.)[rank * 2:rank * 2 + 2].view(2, 1).expand(2, 3)
+    assert torch.equal(xr.grad, want), (xr.grad, want)
+    t = torch.ones(3, dtype=torch.float64) * (rank + 1)
+    assert torch.equal(D.all_reduce_sum_(t), torch.full((3,), 3.0, dtype=torch.float64))
     out[rank] = flat.numpy().copy()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -1,8 +1,12 @@
-"""Two ranks sharing ONE GPU (gloo backend, CUDA tensors) drive the real HIP Trainer through one step:
-exercises dist.init_from_env, batch sharding and GradExchange's side-stream ordering on the device.
-Checks: both ranks end with bit-identical parameters (same averaged gradients, same Adam), and the
-discriminators -- which have no batch coupling -- match a single-process step on the global batch."""
-import argparse
+"""Data-parallel Trainer on the device: N ranks drive the real HIP Trainer through one step.
+
+  * two ranks sharing ONE GPU over gloo (CUDA tensors): dist.init_from_env, rank-0 broadcast of the initial model, batch
+    sharding and GradExchange's side-stream ordering -- ranks stay in lock step, the discriminators (no batch coupling)
+    match a single-process step on the global batch;
+  * dp_mode="global" (cross-replica conditional batch norm + gathered condition rows): the two ranks reproduce ONE
+    process on the global batch -- six losses and every gradient of G, D_s and D_t;
+  * the same over RCCL (backend nccl, one rank per GPU) whenever at least two GPUs are visible.
+"""
 import os
 import socket
 import subprocess
@@ -19,52 +23,72 @@ import argparse, os, sys, torch
 sys.path.insert(0, sys.argv[1])
 from dvd_gan_amd import dist as D
 from dvd_gan_amd.train_step import Trainer
+mode = sys.argv[3]
 rank, world, dev = D.init_from_env()
 cfg = argparse.Namespace(adv_loss="hinge", z_dim=16, g_chn=2, ds_chn=2, dt_chn=2, n_frames=8, lr_schr="const",
                          total_epoch=1, d_iters=1, batch_size=4 // world, g_lr=2e-3, d_lr=2e-3, beta1=0.0, beta2=0.9,
                          n_class=3, k_sample=4)
-torch.manual_seed(0)
-tr = Trainer([], cfg, device=dev, compute_dtype=torch.float32)
+torch.manual_seed(100 * rank)          # DIFFERENT initial weights per rank: the Trainer must broadcast rank 0's
+tr = Trainer([], cfg, device=dev, compute_dtype=torch.float32, dp_mode=mode)
+if world == 1:                         # single process: the model rank 0 of the 2-rank run starts from
+    pass
 g = torch.Generator().manual_seed(1)
 real = torch.rand(4, 3, 8, 64, 64, generator=g) * 2 - 1
 labels = torch.randint(0, 3, (4,), generator=g)
 z = torch.randn(4, 16, generator=g); zc = torch.randint(0, 3, (4,), generator=g)
 draws = {"perm_real": torch.arange(8), "z": D.shard(z, rank, world), "z_class": D.shard(zc, rank, world),
          "perm_fake": torch.arange(8).flip(0)}
+grads = {}
+for tag, net, opt in (("Ds", tr.D_s, tr.ds_optimizer), ("Dt", tr.D_t, tr.dt_optimizer), ("G", tr.G, tr.g_optimizer)):
+    def stepper(net=net, tag=tag, orig=opt.step):
+        grads[tag] = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+        orig()
+    opt.step = stepper
+ids = [tr.frame_gen.initial_seed()] if tr.frame_gen is not None else []
 losses = tr.train_step(D.shard(real, rank, world), D.shard(labels, rank, world), draws)
 torch.cuda.synchronize()
 out = {"Ds": {k: v.detach().cpu() for k, v in tr.D_s.state_dict().items()},
        "Dt": {k: v.detach().cpu() for k, v in tr.D_t.state_dict().items()},
        "G": {k: v.detach().cpu() for k, v in tr.G.state_dict().items()},
-       "losses": [float(v.detach()) for v in losses]}
-torch.save(out, sys.argv[2] + f".{world}.{rank}")
+       "losses": [float(v.detach()) for v in losses], "grads": grads, "frame_seed": ids}
+torch.save(out, sys.argv[2] + f".{mode}.{world}.{rank}")
 if world > 1:
     torch.distributed.barrier(); torch.distributed.destroy_process_group()
 '''
 
 
-def _run(world, tmp):
+def _run(world, tmp, mode="replica", backend="gloo"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = os.path.join(tmp, "worker.py")
     open(script, "w").write(WORKER)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), DVD_SHARE_GPU0="1", DVD_DIST_BACKEND="gloo")
-        procs.append(subprocess.Popen([sys.executable, script, ROOT, os.path.join(tmp, "out")], env=env))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if backend == "gloo":
+            env.update(DVD_SHARE_GPU0="1", DVD_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, script, ROOT, os.path.join(tmp, "out"), mode], env=env))
     for p in procs:
-        assert p.wait(timeout=300) == 0
-    return [torch.load(os.path.join(tmp, f"out.{world}.{r}")) for r in range(world)]
+        assert p.wait(timeout=600) == 0
+    return [torch.load(os.path.join(tmp, f"out.{mode}.{world}.{r}")) for r in range(world)]
 
 
-def test_two_ranks_one_gpu_match_each_other_and_the_global_batch(tmp_path):
-    two = _run(2, str(tmp_path))
-    one = _run(1, str(tmp_path))[0]
+def _single(tmp):
+    """One process on the global batch, started from the weights rank 0 draws (seed 0)."""
+    return _run(1, tmp)[0]
+
+
+def _check_lock_step(two):
     for net in ("G", "Ds", "Dt"):
         for k, v in two[0][net].items():
             if "running_" in k:
                 continue                  # batch-norm statistics are per replica (= nn.DataParallel semantics)
             assert torch.equal(v, two[1][net][k]), (net, k)            # ranks stay in lock step
+    assert two[0]["frame_seed"] == two[1]["frame_seed"] and len(two[0]["frame_seed"]) == 1
+
+
+def _check_replica_mode(two, one):
+    _check_lock_step(two)
     # D_s: its update only depends on D_s gradients (means over equal shards) when the fake inputs agree;
     # fake videos differ between 1 and 2 ranks only through per-replica batch-norm statistics in G, so the
     # REAL-data half is exact; compare D parameters loosely and the real-data losses tightly.
@@ -74,3 +98,46 @@ def test_two_ranks_one_gpu_match_each_other_and_the_global_batch(tmp_path):
         for k, v in one[net].items():
             if v.is_floating_point() and not k.endswith(("weight_u", "weight_v")):
                 assert float((two[0][net][k] - v).abs().max()) < 5e-3, (net, k)      # <= 2.5 Adam steps of lr
+
+
+def _check_global_mode(two, one):
+    """N ranks == 1 rank: losses (mean of the per-rank means), every gradient after the exchange, BN running statistics."""
+    for k, v in two[0]["G"].items():
+        assert torch.equal(v, two[1]["G"][k]), k                          # now the BN buffers agree as well
+    for i in range(6):
+        assert abs(0.5 * (two[0]["losses"][i] + two[1]["losses"][i]) - one["losses"][i]) < 2e-5, i
+    worst = 0.0
+    for net in ("Ds", "Dt", "G"):
+        ref = one["grads"][net]
+        scale = max(float(v.abs().max()) for v in ref.values())
+        for k, v in ref.items():
+            got = two[0]["grads"][net][k]
+            assert torch.equal(got, two[1]["grads"][net][k]), (net, k)
+            if float(v.abs().max()) < 1e-4 * scale:
+                continue
+            r = float((got.double() - v.double()).norm() / v.double().norm())
+            worst = max(worst, r)
+            assert r < 2e-3, (net, k, r)
+    for k, v in one["G"].items():
+        if "running_" in k:
+            assert float((two[0]["G"][k] - v).abs().max()) < 1e-5, k
+    return worst
+
+
+def test_two_ranks_one_gpu_match_each_other_and_the_global_batch(tmp_path):
+    _check_replica_mode(_run(2, str(tmp_path)), _single(str(tmp_path)))
+
+
+def test_two_ranks_global_mode_equal_one_process_on_the_global_batch(tmp_path):
+    _check_global_mode(_run(2, str(tmp_path), mode="global"), _single(str(tmp_path)))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL path needs two GPUs (one rank per GPU)")
+@pytest.mark.parametrize("mode", ["replica", "global"])
+def test_two_gpus_over_rccl(tmp_path, mode):
+    two = _run(2, str(tmp_path), mode=mode, backend="nccl")
+    one = _single(str(tmp_path))
+    if mode == "replica":
+        _check_replica_mode(two, one)
+    else:
+        _check_global_mode(two, one)

@@ -357,3 +357,97 @@ def test_discriminators_at_128x128_frames(dtype):
     v = torch.rand(B, 3, T, 64, 64) * 2 - 1                   # vid_downsample of 128 x 128 frames
     with torch.no_grad():
         assert rel(Dt.to(DEV)(v.to(DEV), cls.to(DEV)), O.temporal_disc(sdt, v, cls)) < ft
+
+
+# ------------------------------------------------------------------ ConvGRU state carry (BASELINE configs[4]; ConvGRU.py:104)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_convgru_cell_backward_through_supplied_state(golden, dtype):
+    """Golden F4 `cell`: y = cell(x, h) of the reference with a NON-zero incoming state -- output, d/dx, d/dh and every
+    parameter gradient (the recurrent half of the weights sees h at step 0)."""
+    from dvd_gan_amd.gen_net import ConvGRUCell
+    g = sub(golden("f4_convgru"), "cell")
+    cell = load(ConvGRUCell(8, 16, 5), sub(g, "sd0"))
+    x, h = t(g["in.x"], True), t(g["in.h"], True)
+    y = ncl(cell.run(cl(x, dtype), 1, False, cl(h, dtype)), 16)
+    ft, gt = TOL[dtype]
+    assert rel(y, g["out.y"]) < ft
+    y.backward(t(g["in.gy"]))
+    assert rel(x.grad, g["grad.x"]) < gt
+    assert rel(h.grad, g["grad.h"]) < gt
+    check_param_grads(cell, {k: v for k, v in sub(g, "grad").items() if k not in ("x", "h")}, gt)
+
+
+def _oracle_gru_with_state(sd, xs, hidden):
+    from oracle import dvdgan_cpu as O
+    state, outs = hidden, []
+    for step in range(xs.shape[0]):
+        state = O.convgru(sd, "", xs[step], state)
+        outs.append(state[-1])
+    return torch.stack(outs)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_convgru_stack_state_carry_vs_oracle(golden, dtype):
+    """3-layer ConvGRU over T=4 started from supplied per-layer states (one layer left at None = zeros): sequence output,
+    d/dx, d/dh0 of each layer and all parameter gradients against the oracle (weights of golden F4 `gru`)."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.gen_net import ConvGRU
+    g = sub(golden("f4_convgru"), "gru")
+    torch.manual_seed(11)
+    xs = torch.as_tensor(g["in.xs"])                            # [T,B,8,8,4]
+    T, B = xs.shape[:2]
+    h0 = [torch.randn(B, 8, 8, 4), None, torch.randn(B, 8, 8, 4)]
+    gy = torch.as_tensor(g["in.gy"])
+    sd = O.make_state(sub(g, "sd0"))
+    xr = xs.clone().requires_grad_(True)
+    hr = [None if h is None else h.clone().requires_grad_(True) for h in h0]
+    want = _oracle_gru_with_state(sd, xr, hr)
+    want.backward(gy)
+    gru = load(ConvGRU(8, [8, 16, 8], [3, 5, 5], 3), sub(g, "sd0"))
+    xg = xs.to(DEV).requires_grad_(True)
+    hg = [None if h is None else h.to(DEV).requires_grad_(True) for h in h0]
+    outs = gru.run(cl(xg.reshape(T * B, *xs.shape[2:]), dtype), T, False, [None if h is None else cl(h, dtype) for h in hg])
+    y = ncl(outs[-1], 8).view(T, B, 8, *xs.shape[3:])
+    ft, gt = TOL[dtype]
+    assert rel(y, want.detach()) < ft
+    y.backward(gy.to(DEV))
+    assert rel(xg.grad, xr.grad) < gt
+    for a, b in zip(hg, hr):
+        if a is not None:
+            assert rel(a.grad, b.grad) < gt
+    check_param_grads(gru, {k: v.grad.numpy() for k, v in sd.items() if v.grad is not None}, gt)
+
+
+def test_generator_with_carried_states_vs_oracle():
+    """Generator.forward(z, class_id, hidden): initial states for two of the four ConvGRUs (frame-conditional variant),
+    exact mode, ch=2, T=4, B=2 against oracle.generator(hidden=...): clips, d/dh0 and named parameter gradients."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.gen_net import Generator
+    torch.manual_seed(17)
+    ch, T, B, ncls, zd = 2, 4, 2, 3, 12
+    G = Generator(zd, 4, ncls, ch, T, compute_dtype=torch.float32)
+    sd = O.make_state({k: v.detach().clone() for k, v in G.state_dict().items()})
+    z, cls = torch.randn(B, zd), torch.randint(0, ncls, (B,))
+    c8 = 8 * ch
+    hid = [[torch.randn(B, c8, 4, 4), torch.randn(B, 2 * c8, 4, 4), None], None, None,
+           [None, torch.randn(B, 8 * ch, 32, 32), torch.randn(B, 4 * ch, 32, 32)]]
+    hr = [None if hl is None else [None if h is None else h.clone().requires_grad_(True) for h in hl] for hl in hid]
+    want = O.generator(sd, z, cls, ch, T, hidden=hr)
+    gy = torch.randn_like(want)
+    want.backward(gy)
+    G = G.to(DEV).train()
+    hg = [None if hl is None else [None if h is None else h.to(DEV).requires_grad_(True) for h in hl] for hl in hid]
+    got = G(z.to(DEV), cls.to(DEV), hg)
+    assert rel(got, want.detach()) < 2e-4
+    got.backward(gy.to(DEV))
+    for hl_g, hl_r in zip(hg, hr):
+        if hl_g is None:
+            continue
+        for a, b in zip(hl_g, hl_r):
+            if a is not None:
+                assert rel(a.grad, b.grad) < 2e-3
+    for name in ("conv.0.cells.0.update_gate.weight", "conv.0.cells.1.out_gate.weight", "conv.9.cells.2.reset_gate.weight",
+                 "conv.9.cells.1.update_gate.weight", "affine_transfrom.weight"):
+        assert rel(dict(G.named_parameters())[name].grad, sd[name].grad) < 2e-3, name
+    with pytest.raises(ValueError):
+        G(z.to(DEV), cls.to(DEV), [[None], None, None, None])
