@@ -12,6 +12,77 @@ from . import kern as K
 from . import lib as L
 
 
+# ------------------------------------------------------------------ weight gradients on a side stream
+# Weight gradients are leaves of the backward pass: nothing downstream of them runs before the optimizer.  When a
+# parameter's .grad already exists as a persistent fp32 buffer (optim.FlatAdam keeps every .grad as a view of one flat
+# buffer) the weight-gradient kernels -- and the spectral-norm backward that follows them -- accumulate STRAIGHT INTO
+# that buffer on a second, lower-priority HIP stream instead of returning a fresh tensor through autograd:
+#   * the ~700 zeros_like / accumulate launches per step of the autograd route disappear;
+#   * the big MFMA-bound weight-gradient launches fill the CUs the serial part of the backward pass leaves idle (the
+#     48-step BPTT of the 4x4 / 8x8 ConvGRUs runs 512-workgroup launches of 15-70 us back to back) and overlap the
+#     HBM-bound CBN / gate kernels.
+# `join_side()` (main stream waits for the side stream) must run before the gradients are read: Trainer does it after
+# every backward().  Parameters without a persistent .grad (stock optimizers with zero_grad(set_to_none=True), module
+# tests) take the autograd route unchanged.
+_SIDE = {"on": False, "stream": None}
+
+
+def direct_weight_grads(flag):
+    """Switch the side-stream / direct-accumulation route on or off (Trainer turns it on; DVD_SIDE_WGRAD=0 vetoes)."""
+    import os
+    _SIDE["on"] = bool(flag) and os.environ.get("DVD_SIDE_WGRAD", "1") != "0"
+
+
+def side_stream():
+    if _SIDE["stream"] is None:
+        lo, hi = 0, 0
+        try:
+            lo, hi = torch.cuda.Stream.priority_range()          # (least, greatest) priority; smaller = more urgent
+        except Exception:
+            pass
+        _SIDE["stream"] = torch.cuda.Stream(priority=lo)
+    return _SIDE["stream"]
+
+
+def join_side():
+    """The current stream waits for everything queued on the weight-gradient stream."""
+    if _SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+
+
+def _direct(*params):
+    """True when every given parameter has a persistent fp32 .grad the kernels can accumulate into."""
+    if not _SIDE["on"]:
+        return False
+    for p in params:
+        if p is None:
+            continue
+        g = getattr(p, "grad", None)
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not p.requires_grad:
+            return False
+    return True
+
+
+class _on_side:
+    """with _on_side(t1, t2, ...): kernels launched inside run on the side stream, ordered after everything queued on
+    the current stream so far; the listed tensors (allocated on the current stream) are kept alive for it."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        side = side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            t.record_stream(side)
+        self.cm = torch.cuda.stream(side)
+        self.cm.__enter__()
+        return side
+
+    def __exit__(self, *exc):
+        return self.cm.__exit__(*exc)
+
+
 # ------------------------------------------------------------------ boundary layout
 class ToChannelsLast(Function):
     """fp32 [F, C, *spatial] -> [F', *spatial, pad8(C)]   (swap=(A,B): frame (a,b) -> (b,a))"""
@@ -59,6 +130,7 @@ class Conv(Function):
                            relu_in=spec.relu_in)
         ctx.spec, ctx.pk, ctx.sigma = spec, pk, spec.sigma
         ctx.has_res = res is not None
+        ctx.params = (w, b)                      # the Parameter objects themselves (their .grad buffers)
         ctx.save_for_backward(x, w, y if spec.act != L.ACT_NONE else None)
         return y
 
@@ -78,7 +150,19 @@ class Conv(Function):
                     dx = K.act_backward(dx, x, L.ACT_RELU)
             else:
                 dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None)
-        if ctx.needs_input_grad[1]:
+        wp, bp = ctx.params
+        if ctx.needs_input_grad[1] and _direct(wp, bp if ctx.needs_input_grad[2] else None):
+            # side stream, straight into the persistent .grad buffers (see the note at the top of this file)
+            with _on_side(x, dy, w, ctx.sigma):
+                dbp = bp.grad if (ctx.needs_input_grad[2] and bp is not None) else None
+                if spec.sn is not None:
+                    G = torch.zeros_like(w)
+                    K.conv_wgrad(x, dy, G, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp)
+                    u, v = spec.sn        # CURRENT u / v on purpose (reference quirk 7): no forward runs before the join
+                    K.sn_backward(G, w, u, v, ctx.sigma, out=wp.grad)
+                else:
+                    K.conv_wgrad(x, dy, wp.grad, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp)
+        elif ctx.needs_input_grad[1]:
             G = torch.zeros_like(w)
             if ctx.needs_input_grad[2]:           # bias gradient rides along in the wgrad kernel
                 db = torch.zeros(spec.cout, dtype=torch.float32, device=dy.device)
@@ -201,6 +285,7 @@ class ConvGRULayer(Function):
         d.ws = ws.data_ptr()
         L.check(lib.dvd_convgru_layer_forward(C.byref(d), L.stream()))
         ctx.save_for_backward(x, wu, wr, wo, h_all, u_all, r_all, o_all, hr_all, h0)
+        ctx.params = (wu, bu, wr, br, wo, bo)
         ctx.packs = (px, pur, po)
         ctx.meta = (T, B, S1, S2, hid, cin, k, shared_x, ws.numel())
         return h_all.view(T * B, S1, S2, hid)
@@ -231,33 +316,44 @@ class ConvGRULayer(Function):
         # ---- everything below is batched over all T steps ----
         dgx = K.sum_leading(dg.view(T, -1)).view(B, S1, S2, 3 * hid) if shared_x else dg
         dx = K.conv_forward(dgx, px.wd, (k, k), px.cip) if ctx.needs_input_grad[0] else None
-        grads = []
         ctot = cin + hid
         hflat = h_all.view(T * B, S1, S2, hid)
         hrflat = hr_all.view(T * B, S1, S2, hid)
-        db3 = torch.zeros(3 * hid, dtype=torch.float32, device=dev)
-        for g, w in enumerate((wu, wr, wo)):
-            dw = torch.zeros_like(w)
-            K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot,
-                         dbias=db3[g * hid:(g + 1) * hid])
-            if h0 is not None:
-                # step 0 read the supplied state: h0 (update / reset) or h0 * r_0 = hr_all[0] (out gate)
-                K.conv_wgrad(h0 if g < 2 else hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin,
-                             dw_ci_tot=ctot, frames=B, x_row0=0, dy_row0=0)
-            if T > 1:
-                # h-part: steps 1..T-1 read h_{t-1} (update/reset) or h_{t-1}*r_t (out gate)
-                if g < 2:
-                    K.conv_wgrad(hflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
-                                 frames=(T - 1) * B, x_row0=0, dy_row0=B)
-                else:
-                    K.conv_wgrad(hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
-                                 frames=(T - 1) * B, x_row0=B, dy_row0=B)
-            grads.append(dw)
+        wparams = ctx.params[0::2]
+        bparams = ctx.params[1::2]
+        direct = _direct(*ctx.params)
+
+        def gate_wgrads(dws, dbs):
+            """dws[g] / dbs[g]: fp32 buffers (reference layouts) the kernels ACCUMULATE into"""
+            for g in range(3):
+                dw = dws[g]
+                K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot, dbias=dbs[g])
+                if h0 is not None:
+                    # step 0 read the supplied state: h0 (update / reset) or h0 * r_0 = hr_all[0] (out gate)
+                    K.conv_wgrad(h0 if g < 2 else hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin,
+                                 dw_ci_tot=ctot, frames=B, x_row0=0, dy_row0=0)
+                if T > 1:
+                    # h-part: steps 1..T-1 read h_{t-1} (update/reset) or h_{t-1}*r_t (out gate)
+                    if g < 2:
+                        K.conv_wgrad(hflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
+                                     frames=(T - 1) * B, x_row0=0, dy_row0=B)
+                    else:
+                        K.conv_wgrad(hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
+                                     frames=(T - 1) * B, x_row0=B, dy_row0=B)
+
+        if direct:
+            with _on_side(x, dgx, dg, h_all, hr_all, h0):
+                gate_wgrads([p.grad for p in wparams], [p.grad for p in bparams])
+            grads, dbl = [None, None, None], [None, None, None]
+        else:
+            db3 = torch.zeros(3 * hid, dtype=torch.float32, device=dev)
+            grads = [torch.zeros_like(w) for w in (wu, wr, wo)]
+            gate_wgrads(grads, [db3[g * hid:(g + 1) * hid] for g in range(3)])
+            dbl = [db3[:hid].clone(), db3[hid:2 * hid].clone(), db3[2 * hid:].clone()]
         dh0 = None
         if dh0_32 is not None:
             dh0 = dh0_32.view(h0.shape) if h0.dtype == torch.float32 else K.convert(dh0_32, h0.dtype).view(h0.shape)
-        return (dx, grads[0], db3[:hid].clone(), grads[1], db3[hid:2 * hid].clone(), grads[2], db3[2 * hid:].clone(),
-                None, None, dh0)
+        return (dx, grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2], None, None, dh0)
 
 
 # ------------------------------------------------------------------ attention / head / loss

@@ -310,8 +310,9 @@ def sn_power_iter(w_bar, u, v, sigma=None):
     return sigma
 
 
-def sn_backward(G, w_bar, u, v, sigma):
-    dW = torch.zeros_like(w_bar)
+def sn_backward(G, w_bar, u, v, sigma, out=None):
+    """dL/dW_bar from G = dL/d(W_bar / sigma); `out`: fp32 buffer the result is ADDED to (default: a fresh zero tensor)."""
+    dW = torch.zeros_like(w_bar) if out is None else out
     scratch = torch.empty(1, dtype=torch.float32, device=w_bar.device)
     h = w_bar.shape[0]
     L.check(L.lib().dvd_sn_backward(L.ptr(G), L.ptr(w_bar), L.ptr(u), L.ptr(v), L.ptr(sigma), h, w_bar.numel() // h,

@@ -101,6 +101,7 @@ class Trainer(object):
         self.log_epoch = getattr(c, "log_epoch", 1)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.compute_dtype, self.latent_dim = compute_dtype, latent_dim
+        Fn.direct_weight_grads(True)          # weight gradients accumulate into FlatAdam's buffers on a side stream
         self.exchange = GradExchange()
         self.rank = torch.distributed.get_rank() if self.exchange.world > 1 else 0
         self.build_model()
@@ -204,6 +205,7 @@ class Trainer(object):
             ds_loss_fake = self.calc_loss(self.D_s(fake_s.detach(), z_class), False)
             self.reset_grad()
             (ds_loss_real + ds_loss_fake).backward()
+            Fn.join_side()
             ex.start("Ds", self.ds_optimizer.grad)
             # ---------------- D_t (its forward/backward overlaps the D_s gradient exchange)
             real_d, fake_d = vid_downsample(real_videos), vid_downsample(fake_videos)
@@ -214,6 +216,7 @@ class Trainer(object):
             self.ds_lr_scher.step((ds_loss_real + ds_loss_fake) if self._plateau else None)
             self.dt_optimizer.zero_grad()
             (dt_loss_real + dt_loss_fake).backward()
+            Fn.join_side()
             ex.start("Dt", self.dt_optimizer.grad)
             last = _ == self.d_iters - 1
             if not last:
@@ -236,10 +239,12 @@ class Trainer(object):
 
             def on_ready(first_done, self=self, ex=ex):
                 lo = self._g_bounds[first_done]
+                Fn.join_side()                    # the bucket's weight gradients were queued on the side stream
                 ex.start_range("G", self.g_optimizer.grad, lo, self._g_hi)
                 self._g_hi = min(self._g_hi, lo)
             self.G.grad_ready_hook = on_ready
         (g_s_loss + g_t_loss).backward()
+        Fn.join_side()
         if ex.world > 1:
             self.G.grad_ready_hook = None
             ex.start_range("G", self.g_optimizer.grad, 0, self._g_hi)

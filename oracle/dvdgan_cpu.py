@@ -411,3 +411,44 @@ def self_attention_3d(sd, pfx, x):
     att = torch.softmax(torch.bmm(q.transpose(1, 2), k), -1)
     out = torch.bmm(v, att.transpose(1, 2)).view(B, C, T, W, H)
     return sd[pfx + "gamma"] * out + x
+
+
+def separable_attn_cell(sd, pfx, x, axis):
+    """SeparableAttnCell.forward, Attention.py:61-111, for attn_id = axis in 'T' | 'W' | 'H'.  x: [B, C, T, W, H].
+    The reference builds its "attention over one axis" from RAW RESHAPES of contiguous tensors (`.view(B, A, -1)` of a
+    [B, C/2, A, ., .] tensor is not a transpose): restated literally --
+        o  = x with the attended axis swapped into position 2 (T: x itself, W: transpose(2,3), H: transpose(2,4))
+        q  = conv1x1(o)                       -> contiguous [B, C/2, A, d1, d2], REINTERPRETED as [B, A, L]
+        k  = maxpool_(2,1,1)(conv1x1(o))      -> [B, C/2, A/2, d1, d2]          REINTERPRETED as [B, L, A/2]
+        v  = maxpool_(2,1,1)(conv1x1(o))      -> [B, C, A/2, d1, d2]            REINTERPRETED as [B, R, A/2]
+        out = v @ softmax(q @ k)^T            -> [B, R, A], reinterpreted as [B, C, (the other two axes), A] and permuted
+        y  = gamma * out + x"""
+    B, C, T, W, H = x.shape
+    assert T % 2 == 0 and W % 2 == 0 and H % 2 == 0, "T, W, H is not even"
+    if axis == "T":
+        A, o = T, x
+    elif axis == "W":
+        A, o = W, x.transpose(2, 3)
+    else:
+        A, o = H, x.transpose(2, 4)
+    q = F.conv3d(o, sd[pfx + "query_conv.weight"], sd[pfx + "query_conv.bias"]).contiguous().view(B, A, -1)
+    k = F.max_pool3d(F.conv3d(o, sd[pfx + "key_conv.weight"], sd[pfx + "key_conv.bias"]), (2, 1, 1), (2, 1, 1))
+    k = k.contiguous().view(B, -1, A // 2)
+    att = torch.softmax(torch.bmm(q, k), -1)
+    v = F.max_pool3d(F.conv3d(o, sd[pfx + "value_conv.weight"], sd[pfx + "value_conv.bias"]), (2, 1, 1), (2, 1, 1))
+    v = v.contiguous().view(B, -1, A // 2)
+    out = torch.bmm(v, att.transpose(2, 1))
+    if axis == "T":
+        out = out.view(B, C, W, H, T).permute(0, 1, 4, 2, 3)
+    elif axis == "W":
+        out = out.view(B, C, T, H, W).permute(0, 1, 2, 4, 3)
+    else:
+        out = out.view(B, C, T, W, H)
+    return sd[pfx + "gamma"] * out + x
+
+
+def separable_attn(sd, pfx, x):
+    """SeparableAttn.forward, Attention.py:8-21: the T, W and H cells in sequence (keys `model.{0,1,2}.*`)."""
+    for i, axis in enumerate("TWH"):
+        x = separable_attn_cell(sd, f"{pfx}model.{i}.", x, axis)
+    return x

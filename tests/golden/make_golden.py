@@ -248,6 +248,8 @@ def f5_attention(R):
     gy = torch.randn_like(y)
     y.backward(gy)
     st["sep.out.y"], st["sep.in.gy"], st["sep.grad.x"] = npy(y), npy(gy), npy(x.grad)
+    for k, p in sp.named_parameters():
+        st[f"sep.grad.{k}"] = npy(p.grad)
     save("f5_attention", st)
 
 

@@ -258,7 +258,9 @@ def test_bf16_free_running_step(oracle_run):
     tr = make_trainer(g, torch.bfloat16)
     snaps = snapshot_hip_grads(tr)
     fake = {}
-    hook = tr.G.register_forward_hook(lambda m, i, out: fake.setdefault("y", out.detach().float().cpu()))
+    def keep(module, inputs, out):
+        fake["y"] = out.detach().float().cpu()                 # (returns None: the output itself is left alone)
+    hook = tr.G.register_forward_hook(keep)
     losses = [float(v.detach()) for v in tr.train_step(torch.as_tensor(fixture_real(g, 0)), torch.as_tensor(g["in.labels.0"]),
                                                       draws_of(g))]
     hook.remove()

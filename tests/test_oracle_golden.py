@@ -142,6 +142,18 @@ def test_f5_attention3d(golden):
     close(x.grad, g["grad.x"], 1e-4, 1e-5)
 
 
+def test_f5_separable_attention(golden):
+    """SeparableAttn (Attention.py:8-111), reference fixture: output, input gradient, every parameter gradient."""
+    g = sub(golden("f5_attention"), "sep")
+    sd = O.make_state(sub(g, "sd0"))
+    x = t(g["in.x"]).requires_grad_(True)
+    y = O.separable_attn(sd, "", x)
+    close(y, g["out.y"], 1e-5, 1e-6)
+    y.backward(t(g["in.gy"]))
+    close(x.grad, g["grad.x"], 1e-4, 1e-6)
+    check_grads(sd, {k: v for k, v in sub(g, "grad").items() if k != "x"}, 1e-4, 1e-6)
+
+
 # ------------------------------------------------------------------ F6
 @pytest.mark.parametrize("tag,ld,T", [("a", 2, 4), ("b", 4, 4)])
 def test_f6_generator(golden, tag, ld, T):
