@@ -47,6 +47,7 @@ struct ConvK {
     int T, H, W, logH, logW, Hin, Win;
     int kt, kh, kw, kchunks, nk, nsplit, tilesN;
     int up2, relu_in, act, out_f32;
+    int nmajor;                          // tile order: consecutive workgroups (one XCD's run) share the N tile, not the M tile
     size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
     int maxshift;                        // largest |tap shift| in rows
     GruEpi g;                            // optional fused ConvGRU gate epilogue (mode 0 = off)
@@ -270,7 +271,13 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rr = nwg & 7;
         bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
     }
-    const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    // M-major (default): one XCD's contiguous run of tiles shares the activation rows.  N-major, for the recurrent convs of
+    // the 4 x 4 / 8 x 8 stages whose weights (up to 26 MB, re-fetched from the Infinity Cache every time step because a
+    // step's weights exceed the 4 MiB L2) dwarf the activations: a run shares the WEIGHT tile instead, so each weight block
+    // enters one or two L2s rather than all eight.
+    int mt, nt;
+    if (p.nmajor) { const int tilesM = gridDim.x / p.tilesN; nt = bid / tilesM; mt = bid - nt * tilesM; }
+    else { mt = bid / p.tilesN; nt = bid - mt * p.tilesN; }
     const int m0 = mt * BMt, n0 = nt * BNt;
     const int z = blockIdx.z;
     const int per = (p.nk + p.nsplit - 1) / p.nsplit;
@@ -1424,6 +1431,7 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     p.tilesN = wide ? (d->Cout + 255) / 256 : thin ? 1 : (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};
+    p.nmajor = 0;
     {   // extents of the two buffer descriptors (32-bit byte offsets): tensors must stay below 4 GiB
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
         const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;
@@ -1432,6 +1440,8 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         if (wb >= 0xffffffffull) return DVD_E_SHAPE;
         p.in_bytes = inb; p.w_bytes = (unsigned)wb;
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
+        static const int nmaj = getenv("DVD_CONV_NMAJOR") ? atoi(getenv("DVD_CONV_NMAJOR")) : 1;
+        p.nmajor = nmaj && !halo && wb > inb && wb > (4u << 20);      // weights beyond one L2
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;

@@ -207,11 +207,16 @@ int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int
 // Split-K factor that brings a conv with few output tiles up to ~two workgroups per CU (measured on the
 // full step: target 128 -> 948 ms, 256 -> 922, 384 -> 917, 512 -> 913; re-swept with the halo kernels, where a split
 // shape gets the 256 x 128 tile at two workgroups per CU: 512 -> 642 ms, 768 -> 634, 1024 -> 626, 1536 -> 661).
+// Per layer (tools/gru_microbench.py, round 2) the optimum depends on the filter: the 3 x 3 layers have a short K loop
+// (36-72 steps), so a fused gate epilogue without split-K beats a better-filled split launch + gate kernel there
+// (S = 32, h = 128: 13.3 -> 11.1 ms; S = 8 / 16, h = 256: 7.2 -> 5.9 and 11.4 -> 10.6 ms per layer); the 5 x 5 layers
+// keep 1024 (S = 16, h = 512: 52.0 vs 60.2 ms at 512).
 extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps) {
     const int bk = dtype == DVD_BF16 ? 32 : 16;
     const long long nk = (long long)ntaps * ((C + bk - 1) / bk);
     const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    static const long long target = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 1024;
+    static const long long target_env = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 0;
+    const long long target = target_env ? target_env : (ntaps <= 9 ? 512 : 1024);
     long long ns = (target + tiles - 1) / tiles;
     static const long long cap = getenv("DVD_NS_CAP") ? atoll(getenv("DVD_NS_CAP")) : 16;
     if (ns > cap) ns = cap;

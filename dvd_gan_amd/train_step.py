@@ -102,6 +102,9 @@ class Trainer(object):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.compute_dtype, self.latent_dim = compute_dtype, latent_dim
         Fn.direct_weight_grads(True)          # weight gradients accumulate into FlatAdam's buffers on a side stream
+        self._chain = None
+        if torch.cuda.is_available() and os.environ.get("DVD_CHAIN_PRIO", "1") != "0":
+            self._chain = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
         self.exchange = GradExchange()
         self.rank = torch.distributed.get_rank() if self.exchange.world > 1 else 0
         self.build_model()
@@ -185,7 +188,22 @@ class Trainer(object):
         """real_videos [B,3,T,H,W], real_labels [B].  `draws` (tests): dict with the reference's RNG
         draws perm_real / z / z_class / perm_fake.  `hidden`: initial ConvGRU states for the generator
         (Generator.forward, frame-conditional variant).  Returns the six loss terms as device scalars:
-        ds_real, ds_fake, dt_real, dt_fake, g_s, g_t."""
+        ds_real, ds_fake, dt_real, dt_fake, g_s, g_t.
+        The step's dependent chain runs on a HIGH-priority stream so its (often small) launches are dispatched ahead of
+        the bulk weight-gradient work queued on the normal-priority side stream; the caller's stream is ordered before
+        and after the step, so nothing changes for it."""
+        if self._chain is None:
+            return self._train_step(real_videos, real_labels, draws, hidden)
+        outer = torch.cuda.current_stream()
+        self._chain.wait_stream(outer)
+        with torch.cuda.stream(self._chain):
+            out = self._train_step(real_videos, real_labels, draws, hidden)
+        outer.wait_stream(self._chain)
+        for v in out:
+            v.record_stream(outer)
+        return out
+
+    def _train_step(self, real_videos, real_labels, draws=None, hidden=None):
         real_videos = real_videos.to(self.device).permute(0, 2, 1, 3, 4).contiguous()
         real_labels = self._check_labels(real_labels).to(self.device)
         T, k = self.n_frames, self.k_sample

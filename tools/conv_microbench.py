@@ -17,17 +17,41 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (3072, 16, 1536, 256, 5, False),  # its backward-data
     (3072, 16, 256, 256, 3, False),   # GResBlock 3x3
     (3072, 32, 128, 128, 3, False),
+    (64, 32, 128, 256, 3, False),     # 8: gru3.l0 [u|r] h-path, one step
+    (64, 32, 128, 128, 3, False),     # 9: gru3.l0 out-gate h-path
+    (64, 16, 256, 512, 3, False),     # 10: gru2.l0 [u|r]
+    (64, 16, 256, 256, 3, False),     # 11
+    (64, 32, 256, 512, 5, False),     # 12: gru3.l1 [u|r]
+    (64, 8, 256, 512, 3, False),      # 13: gru1.l0 [u|r]
+    (64, 4, 256, 512, 3, False),      # 14: gru0.l0 [u|r]
+    (64, 32, 32, 256, 3, False),      # 15..18: K sweep at fixed M / Cout (fixed cost vs per-K cost of a one-round launch)
+    (64, 32, 64, 256, 3, False),
+    (64, 32, 256, 256, 3, False),
+    (64, 32, 512, 256, 3, False),
+    (128, 32, 128, 256, 3, False),    # 19, 20: two and four rounds of the same tiles
+    (256, 32, 128, 256, 3, False),
 ]
 
 
 def bench(fn, iters):
+    """`iters` back-to-back launches replayed from a HIP graph (no Python / ctypes time between launches: the recurrent
+    convolutions take 15-70 us, less than a ctypes call)."""
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(iters):
+                fn()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(iters):
-        fn()
+    graph.replay()
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) / iters

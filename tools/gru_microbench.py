@@ -1,0 +1,79 @@
+"""Times the SERIAL part of each ConvGRU layer of config C2 (B=64, T=48): the in-library time loops
+dvd_convgru_layer_forward / _backward (recurrent convolutions + gate math), without the batched x-path / weight-gradient
+launches around them.  HIP events on the launch stream, median of `iters` runs.
+usage: python tools/gru_microbench.py [iters] [layer indices, e.g. 0,1,2] [B] [T]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dvd_gan_amd import kern as K
+from dvd_gan_amd import lib as L
+
+# (name, S, cin, hidden, k) of the 12 ConvGRU layers at ch=32 (Generator.py:39,43,47,51)
+LAYERS = [("gru0.l0", 4, 256, 256, 3), ("gru0.l1", 4, 256, 512, 5), ("gru0.l2", 4, 512, 256, 3),
+          ("gru1.l0", 8, 256, 256, 3), ("gru1.l1", 8, 256, 512, 5), ("gru1.l2", 8, 512, 256, 3),
+          ("gru2.l0", 16, 256, 256, 3), ("gru2.l1", 16, 256, 512, 5), ("gru2.l2", 16, 512, 256, 3),
+          ("gru3.l0", 32, 128, 128, 3), ("gru3.l1", 32, 128, 256, 5), ("gru3.l2", 32, 256, 128, 5)]
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    sel = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2] else range(len(LAYERS))
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    T = int(sys.argv[4]) if len(sys.argv) > 4 else 48
+    dev, dt = "cuda", torch.bfloat16
+    lib = L.lib()
+    tot_f = tot_b = 0.0
+    for name, S, cin, hid, k in [LAYERS[i] for i in sel]:
+        M = B * S * S
+        gx = (torch.randn(T, M, 3 * hid, device=dev) * 0.5).to(dt)
+        pur = K.PackedConv(dt, 2 * hid, hid, (k, k), dev).fill(torch.randn(2 * hid, hid, k, k, device=dev) * (0.5 / (hid * k * k) ** 0.5))
+        po = K.PackedConv(dt, hid, hid, (k, k), dev).fill(torch.randn(hid, hid, k, k, device=dev) * (0.5 / (hid * k * k) ** 0.5))
+        mk = lambda: torch.empty(T, M, hid, dtype=dt, device=dev)
+        h_all, u_all, r_all, o_all, hr_all = mk(), mk(), mk(), mk(), mk()
+        h32 = torch.empty(2, M, hid, dtype=torch.float32, device=dev)
+        ntaps = k * k
+        ns = [lib.dvd_conv_pick_nsplit(L.BF16, C.c_longlong(M), co, ci, ntaps) for co, ci in ((2 * hid, hid), (hid, hid), (hid, 2 * hid))]
+        ws = torch.empty(max(ns[0] * 2, ns[1], ns[2]) * M * hid, dtype=torch.float32, device=dev)
+        d = L.GruDesc()
+        d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.BF16, T, B, S, S, hid, k
+        d.gx_stride = M * 3 * hid
+        d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
+        d.wd_ur, d.wd_o = pur.wd.data_ptr(), po.wd.data_ptr()
+        d.h_all, d.u_all, d.r_all, d.o_all, d.hr_all = (t.data_ptr() for t in (h_all, u_all, r_all, o_all, hr_all))
+        d.h32, d.ws = h32.data_ptr(), ws.data_ptr()
+        dh = (torch.randn(T, M, hid, device=dev) * 0.1).to(dt)
+        dg = torch.empty(T, M, 3 * hid, dtype=dt, device=dev)
+        carry = torch.empty(M, hid, dtype=torch.float32, device=dev)
+        d.dh_out, d.dg, d.carry = dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        tf = timed(lambda: L.check(lib.dvd_convgru_layer_forward(C.byref(d), st)), iters)
+        tb = timed(lambda: L.check(lib.dvd_convgru_layer_backward(C.byref(d), st)), iters)
+        fl_f = 2.0 * (T - 1) * M * hid * 3 * hid * ntaps
+        fl_b = fl_f
+        tot_f += tf; tot_b += tb
+        print(f"{name} S={S:2d} h={hid:3d} k={k} ns(ur,o,dur)={ns}: fwd {tf:7.2f} ms ({fl_f / tf / 1e9:6.0f} TF/s, {tf / T * 1e3:6.1f} us/step)"
+              f"   bwd {tb:7.2f} ms ({fl_b / tb / 1e9:6.0f} TF/s, {tb / T * 1e3:6.1f} us/step)", flush=True)
+    print(f"total fwd {tot_f:.2f} ms  bwd {tot_b:.2f} ms  sum {tot_f + tot_b:.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
