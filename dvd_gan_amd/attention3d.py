@@ -50,3 +50,54 @@ class SelfAttention(nn.Module):
         qkv = QKVConv.apply(xc, wq, self.query_conv.bias, wk, self.key_conv.bias, wv, self.value_conv.bias, spec, dq, dqp)
         kv = Fn.MaxPool3d.apply(qkv)                                         # the q columns ride along unused
         return Fn.SelfAttentionKV.apply(xc, qkv, kv, self.gamma, dq, C_)
+
+
+class SeparableAttnCell(nn.Module):
+    """Attention.py:24-111.  Keys: gamma, {query,key,value}_conv.{weight [Cout,Cin,1,1,1], bias}.  `attn_id` in 'T' | 'W' | 'H'."""
+
+    def __init__(self, in_dim, attn_id=None, compute_dtype=torch.bfloat16):
+        super().__init__()
+        if attn_id not in ("T", "W", "H"):
+            raise ValueError("attn_id must be 'T', 'W' or 'H'")
+        self.attn_id, self.chanel_in, self.compute_dtype = attn_id, in_dim, compute_dtype
+        self.query_conv = PlainConv(in_dim, in_dim // 2, (1, 1, 1))
+        self.key_conv = PlainConv(in_dim, in_dim // 2, (1, 1, 1))
+        self.value_conv = PlainConv(in_dim, in_dim, (1, 1, 1))
+        self.gamma = nn.Parameter(torch.zeros((1,)))
+
+    def forward(self, x):
+        B, C_, T, W, H = x.shape
+        xc = Fn.ToChannelsLast.apply(x, self.compute_dtype, None)
+        return Fn.FromChannelsLast.apply(self.run(xc), C_, None)
+
+    def run(self, xc):
+        """channels-last [B, T, W, H, Cp] in / out"""
+        B, T, W, H, _ = xc.shape
+        assert T % 2 == 0 and W % 2 == 0 and H % 2 == 0, "T, W, H is not even"
+        C_, dq = self.chanel_in, self.chanel_in // 2
+        dqp = K.pad8(dq)
+        ctot = 2 * dqp + C_
+        spec = Fn.ConvSpec((1, 1), ctot, C_)
+        pk = K.PackedConv(xc.dtype, ctot, C_, (1, 1), xc.device)
+        wq, wk, wv = (c.weight.view(c.cout, c.cin, 1, 1) for c in (self.query_conv, self.key_conv, self.value_conv))
+        pk.fill(wq.data, co_off=0).fill(wk.data, co_off=dqp).fill(wv.data, co_off=2 * dqp)
+        spec.pack = pk
+        qkv = QKVConv.apply(xc, wq, self.query_conv.bias, wk, self.key_conv.bias, wv, self.value_conv.bias, spec, dq, dqp)
+        return Fn.SeparableAttnCellFn.apply(xc, qkv, self.gamma, dq, C_, "TWH".index(self.attn_id))
+
+
+class SeparableAttn(nn.Module):
+    """Attention.py:8-21: the T, W and H cells in sequence; state_dict keys `model.{0,1,2}.*`."""
+
+    def __init__(self, in_dim, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.model = nn.Sequential(*(SeparableAttnCell(in_dim, a, compute_dtype) for a in "TWH"))
+
+    def forward(self, x):
+        xc = Fn.ToChannelsLast.apply(x, self.model[0].compute_dtype, None)
+        return Fn.FromChannelsLast.apply(self.run(xc), x.shape[1], None)
+
+    def run(self, xc):
+        for cell in self.model:
+            xc = cell.run(xc)
+        return xc

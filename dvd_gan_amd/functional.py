@@ -108,6 +108,32 @@ class FromChannelsLast(Function):
         return K.to_cl(g.contiguous(), ctx.dtype, ctx.swap), None, None
 
 
+class SwapFrameOrder(Function):
+    """[A*B frames, ...] a-major -> b-major (a pure row permutation of a channels-last tensor; (T, B) t-major <-> (B, T)
+    clip-major around the clip-level attention blocks).  Rows are moved as 32-bit words, whatever the storage type."""
+
+    @staticmethod
+    def _perm(A, B, dev):
+        return (torch.arange(B, device=dev).view(B, 1) + torch.arange(A, device=dev).view(1, A) * B).reshape(-1).int()
+
+    @staticmethod
+    def _move(x, idx):
+        F_ = x.shape[0]
+        words = x.contiguous().view(F_, -1).view(torch.float32)
+        out = K.row_copy(words, idx, F_, words.shape[1], scatter=False)
+        return out.view(x.dtype).view(x.shape)
+
+    @staticmethod
+    def forward(ctx, x, A, B):
+        ctx.AB = (A, B)
+        return SwapFrameOrder._move(x, SwapFrameOrder._perm(A, B, x.device))       # out[b*A + a] = x[a*B + b]
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.AB
+        return SwapFrameOrder._move(g.contiguous(), SwapFrameOrder._perm(B, A, g.device)), None, None
+
+
 # ------------------------------------------------------------------ convolution
 class ConvSpec:
     """Static description + per-forward state of one convolution call."""
@@ -450,6 +476,49 @@ class SelfAttentionKV(Function):
                                                   L.ptr(dS), L.ptr(dqkv), L.ptr(dkv), L.ptr(dgamma), C.c_longlong(F_), N, Nk,
                                                   L.stream()))
         return dy, dqkv, dkv, dgamma, None, None
+
+
+class SeparableAttnCellFn(Function):
+    """One SeparableAttnCell (Attention.py:61-111) on channels-last tensors: y = gamma * out + x, with q | k | v the
+    columns [0,dq) | [koff,..) | [voff,..) of the fused projection `qkv` [B,T,W,H,ld]; axis 0 / 1 / 2 = T / W / H."""
+
+    @staticmethod
+    def forward(ctx, x, qkv, gamma, dq, C_real, axis):
+        B, T, W, H, ldx = x.shape
+        koff = K.pad8(dq)
+        voff = 2 * koff
+        N = T * W * H
+        A = (T, W, H)[axis]
+        dev = x.device
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        Qf, Kp, Vp = f32(B * dq * N), f32(B * dq * N // 2), f32(B * C_real * N // 2)
+        ksel, vsel, att = u8(B * dq * N // 2), u8(B * C_real * N // 2), f32(B * A * (A // 2))
+        y = torch.zeros_like(x) if ldx != C_real else torch.empty_like(x)
+        L.check(L.lib().dvd_sepattn_forward(L.dt(x), L.ptr(qkv), qkv.shape[-1], dq, koff, voff, L.ptr(x), ldx, C_real,
+                                            L.ptr(gamma), L.ptr(y), L.ptr(Qf), L.ptr(Kp), L.ptr(Vp), L.ptr(ksel), L.ptr(vsel),
+                                            L.ptr(att), C.c_longlong(B), T, W, H, axis, L.stream()))
+        ctx.save_for_backward(gamma, Qf, Kp, Vp, ksel, vsel, att)
+        ctx.meta = (B, T, W, H, ldx, qkv.shape[-1], dq, C_real, koff, voff, axis, qkv.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        gamma, Qf, Kp, Vp, ksel, vsel, att = ctx.saved_tensors
+        B, T, W, H, ldx, ldq, dq, C_real, koff, voff, axis, qdt = ctx.meta
+        dy = dy.contiguous()
+        dev = dy.device
+        N = T * W * H
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        dO, dS = f32(B * C_real * N), torch.empty_like(att)
+        dQf, dKp, dVp = torch.empty_like(Qf), torch.empty_like(Kp), torch.empty_like(Vp)
+        dqkv = torch.zeros(B, T, W, H, ldq, dtype=qdt, device=dev)
+        dgamma = torch.zeros(1, dtype=torch.float32, device=dev)
+        L.check(L.lib().dvd_sepattn_backward(L.dt(dy), L.ptr(dy), ldx, C_real, dq, L.ptr(gamma), L.ptr(Qf), L.ptr(Kp), L.ptr(Vp),
+                                             L.ptr(ksel), L.ptr(vsel), L.ptr(att), L.ptr(dO), L.ptr(dS), L.ptr(dQf), L.ptr(dKp),
+                                             L.ptr(dVp), L.ptr(dqkv), ldq, koff, voff, L.ptr(dgamma), C.c_longlong(B), T, W, H,
+                                             axis, L.stream()))
+        return dy, dqkv, dgamma, None, None, None
 
 
 class ProjectionHead(Function):

@@ -87,7 +87,11 @@ class Generator(nn.Module):
     .forward(z [B,in_dim] f32, class_id [B] i64) -> [B, T, 3, 16*latent_dim, 16*latent_dim] f32."""
 
     def __init__(self, in_dim=120, latent_dim=4, n_class=4, ch=32, n_frames=48, hierar_flag=False,
-                 compute_dtype=torch.bfloat16):
+                 compute_dtype=torch.bfloat16, self_attn=False, sep_attn=False):
+        """self_attn / sep_attn switch on the two attention blocks the reference defines and imports (Generator.py:10) but
+        leaves commented out: `self.self_attn = SelfAttention(8 * ch)` (:29) over the (T, ld, ld) latent clip after the first
+        ConvGRU, and `SeparableAttn(4 * ch)` (:34, after the block that produces 4*ch channels) over the (T, 8 ld, 8 ld) clip
+        after module 8.  Parameter keys: `self_attn.*`, `sep_attn.model.{0,1,2}.*` (absent when off: reference checkpoints load)."""
         super().__init__()
         if hierar_flag:
             raise NotImplementedError("hierar_flag=True is broken in the reference (Generator.py:66,109)")
@@ -112,6 +116,12 @@ class Generator(nn.Module):
             GResBlock(c4, c4, nc, 1), GResBlock(c4, c2, nc),
         ])
         self.colorize = SpectralNormConv(c2, 3, (3, 3))
+        if self_attn or sep_attn:
+            from .attention3d import SelfAttention, SeparableAttn
+            if self_attn:
+                self.self_attn = SelfAttention(c8, compute_dtype)
+            if sep_attn:
+                self.sep_attn = SeparableAttn(c4, compute_dtype)
         self.dp_global = False                      # data-parallel "global" mode: conditions gathered over the ranks
         self.dp_hooks = False                       # data-parallel trainer sets it: stage-boundary gradient hooks
         self.grad_ready_hook = None                 # callable(first finished module index), armed around backward
@@ -159,6 +169,11 @@ class Generator(nn.Module):
                 y = m.run(y, T, shared_x=(k == 0), hidden=h0)[-1]
             else:
                 y = m.run(y, cond, samp)
+            attn = getattr(self, "self_attn", None) if k == 0 else getattr(self, "sep_attn", None) if k == 8 else None
+            if attn is not None:                      # clip-level attention: frames clip-major around the block
+                S1, S2, Cp = y.shape[1:]
+                clip = Fn.SwapFrameOrder.apply(y, T, B).view(B, T, S1, S2, Cp)
+                y = Fn.SwapFrameOrder.apply(attn.run(clip).view(B * T, S1, S2, Cp), B, T)
             if self.dp_hooks and y.requires_grad and k in self.grad_ready_stages:
                 # fires when the backward pass has produced d/dy: every module after k has all its gradients queued
                 y.register_hook(lambda g_, k_=k: self.grad_ready_hook(k_ + 1) if self.grad_ready_hook else None)

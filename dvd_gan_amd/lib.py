@@ -41,6 +41,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.dvd_strerror.restype = C.c_char_p
         _lib.dvd_conv_wgrad_ws_floats.restype = C.c_longlong
+        _lib.dvd_sepattn_work_floats.restype = C.c_longlong
         if _lib.dvd_abi_version() != ABI_VERSION:
             raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
     return _lib

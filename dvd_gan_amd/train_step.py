@@ -87,7 +87,7 @@ class Trainer(object):
             raise ValueError("dp_mode must be 'replica' or 'global'")
         self.dp_mode = dp_mode
         self.data_loader = data_loader
-        c = config
+        c = self.config = config
         self.adv_loss, self.z_dim = c.adv_loss, c.z_dim
         self.g_chn, self.ds_chn, self.dt_chn = c.g_chn, c.ds_chn, c.dt_chn
         self.n_frames, self.lr_schr = c.n_frames, c.lr_schr
@@ -118,7 +118,9 @@ class Trainer(object):
     # ---- trainer.py:345-366
     def build_model(self):
         dt = self.compute_dtype
-        self.G = Generator(self.z_dim, self.latent_dim, self.n_class, self.g_chn, self.n_frames, compute_dtype=dt).to(self.device)
+        c = self.config
+        self.G = Generator(self.z_dim, self.latent_dim, self.n_class, self.g_chn, self.n_frames, compute_dtype=dt,
+                           self_attn=getattr(c, "g_self_attn", False), sep_attn=getattr(c, "g_sep_attn", False)).to(self.device)
         self.D_s = SpatialDiscriminator(self.ds_chn, self.n_class, compute_dtype=dt).to(self.device)
         self.D_t = TemporalDiscriminator(self.dt_chn, self.n_class, compute_dtype=dt).to(self.device)
         if self.exchange.world > 1 and self.dp_mode == "global":
@@ -137,7 +139,9 @@ class Trainer(object):
     def select_opt_schr(self):
         betas = (self.beta1, self.beta2)
         self.g_optimizer = FlatAdam(self.G.parameters(), self.g_lr, betas)
-        self.G.dp_hooks = self.exchange.world > 1
+        # (the optional attention blocks sit at the END of the parameter order but finish their gradients late in the
+        #  backward pass: with them the generator's gradient goes in one piece)
+        self.G.dp_hooks = self.exchange.world > 1 and not (hasattr(self.G, "self_attn") or hasattr(self.G, "sep_attn"))
         # offset of the first trainable parameter of generator module conv.k in the flat buffers (gradient buckets)
         self._g_bounds, off = {}, 0
         for name, prm in self.G.named_parameters():

@@ -257,6 +257,25 @@ int dvd_maxpool3d(int dtype, const void* x, void* y, long long frames, int To, i
 int dvd_maxpool3d_backward(int dtype, const void* x, const void* dy, void* dx, long long frames, int To, int Ho, int Wo,
                            int ld, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SeparableAttnCell (Module/Attention.py:24-111; the T / W / H cells of SeparableAttn, :8-21): attention along ONE axis of a
+ * [B, T, W, H, C] channels-last clip, built -- like the reference -- from raw reshapes of the contiguous NCDHW projections
+ * (see csrc/sepattn.hip).  q | k | v are columns [0,Cq) | [koff,koff+Cq) | [voff,voff+C) of `qkv` (one fused 1x1 conv);
+ * axis: 0 = T, 1 = W, 2 = H; T, W, H even; attended size / 2 <= 64.  Work arrays are per call, sized by the caller:
+ *   Qf [B][Cq*N], Kp [B][Cq*N/2], Vp [B][C*N/2] fp32, ksel / vsel bytes of the same counts (max-pool winners),
+ *   att [B][A][A/2]   (N = T*W*H; dvd_sepattn_work_floats = floats of Qf + Kp + Vp + att per clip)
+ * backward additionally: dO [B][C*N], dS like att, dQf / dKp / dVp like Qf / Kp / Vp; writes the q | k | v columns of dqkv
+ * and ADDS to dgamma[1].  The residual path (dx += dy) and the 1x1 convolutions belong to the caller.
+ * ---------------------------------------------------------------------------------------- */
+long long dvd_sepattn_work_floats(int T, int W, int H, int axis, int C, int Cq);
+int dvd_sepattn_forward(int dtype, const void* qkv, int ldq, int Cq, int koff, int voff, const void* x, int ldx, int C,
+                        const float* gamma, void* y, float* Qf, float* Kp, float* Vp, unsigned char* ksel,
+                        unsigned char* vsel, float* att, long long B, int T, int W, int H, int axis, void* stream);
+int dvd_sepattn_backward(int dtype, const void* dy, int ldx, int C, int Cq, const float* gamma, const float* Qf,
+                         const float* Kp, const float* Vp, const unsigned char* ksel, const unsigned char* vsel,
+                         const float* att, float* dO, float* dS, float* dQf, float* dKp, float* dVp, void* dqkv, int ldq,
+                         int koff, int voff, float* dgamma, long long B, int T, int W, int H, int axis, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

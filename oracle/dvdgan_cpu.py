@@ -148,13 +148,18 @@ def gresblock(sd, pfx, x, cond, upsample, training=True):
 GEN_STACK = ("gru", "res1", "res2") * 4      # Generator.py:38-55: [ConvGRU, GResBlock, GResBlock(up)] x 4
 
 
-def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True, taps=None, hidden=None):
+def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True, taps=None, hidden=None, self_attn=False,
+              sep_attn=False):
     """Generator.forward, Generator.py:63-120 (hierar_flag=False).
     taps (test aid): a list that receives the input of the first module followed by the output of each of the 12
     modules of `self.conv` ([B*T, C, S, S], b-major frames), each with retain_grad() so a later backward leaves the
     gradient flowing through that point on the tensor.
     hidden (frame-conditional variant): per ConvGRU of the stack (4 entries), None or the list of per-layer states that
-    replaces the `hidden=None` of the first frame (Generator.py:91,96 -> ConvGRU.forward(x, hidden), ConvGRU.py:104-118)."""
+    replaces the `hidden=None` of the first frame (Generator.py:91,96 -> ConvGRU.forward(x, hidden), ConvGRU.py:104-118).
+    self_attn / sep_attn: the two attention blocks the reference defines and imports (Generator.py:10) but leaves commented
+    out (:29 `self.self_attn = SelfAttention(8 * ch)`, :34 `SeparableAttn(4 * ch)` after the block that produces 4*ch
+    channels): SelfAttention over the (T, 4, 4) latent clip after the first ConvGRU, SeparableAttn over the (T, 32, 32) clip
+    after module 8; state keys `self_attn.*` / `sep_attn.model.{0,1,2}.*`."""
     B, T = z.shape[0], n_frames
     class_emb = F.embedding(class_id, sd["embedding.weight"])
     zc = torch.cat([z, class_emb], 1)
@@ -180,6 +185,10 @@ def generator(sd, z, class_id, ch, n_frames, latent_dim=4, training=True, taps=N
             y = torch.stack(frames, 1).reshape(B * T, *frames[0].shape[1:])    # b-major frames
         else:
             y = gresblock(sd, pfx, y, cond, 1 if kind == "res1" else 2, training)
+        if (self_attn and k == 0) or (sep_attn and k == 8):
+            clip = y.view(B, T, *y.shape[1:]).permute(0, 2, 1, 3, 4)           # [B, C, T, W, H]
+            clip = self_attention_3d(sd, "self_attn.", clip) if k == 0 else separable_attn(sd, "sep_attn.", clip)
+            y = clip.permute(0, 2, 1, 3, 4).reshape(B * T, *y.shape[1:])
         tap(y)
     y = F.relu(y)
     y = F.conv2d(y, sn_weight(sd, "colorize.module."), sd["colorize.module.bias"], padding=1)

@@ -445,9 +445,90 @@ def test_generator_with_carried_states_vs_oracle():
             continue
         for a, b in zip(hl_g, hl_r):
             if a is not None:
-                assert rel(a.grad, b.grad) < 2e-3
+                assert rel(a.grad, b.grad) < 1e-2      # ch=2 end-to-end fixture: fp32 rounding amplified ~100x (see GEN_TOL)
     for name in ("conv.0.cells.0.update_gate.weight", "conv.0.cells.1.out_gate.weight", "conv.9.cells.2.reset_gate.weight",
                  "conv.9.cells.1.update_gate.weight", "affine_transfrom.weight"):
         assert rel(dict(G.named_parameters())[name].grad, sd[name].grad) < 1e-2, name
     with pytest.raises(ValueError):
         G(z.to(DEV), cls.to(DEV), [[None], None, None, None])
+
+
+# ------------------------------------------------------------------ SeparableAttn (Attention.py:8-111) and the generator flags
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_separable_attention_golden(golden, dtype):
+    """Reference fixture F5 `sep`: T, W, H cells in sequence on [2, 8, 4, 4, 4] -- output, d/dx, every parameter gradient."""
+    from dvd_gan_amd.attention3d import SeparableAttn
+    g = sub(golden("f5_attention"), "sep")
+    at = load(SeparableAttn(8, compute_dtype=dtype), sub(g, "sd0"))
+    x = t(g["in.x"], True)
+    y = at(x)
+    ft, gt = TOL[dtype]
+    assert rel(y, g["out.y"]) < ft
+    y.backward(t(g["in.gy"]))
+    assert rel(x.grad, g["grad.x"]) < gt
+    check_param_grads(at, {k: v for k, v in sub(g, "grad").items() if k != "x"}, gt)
+
+
+def test_separable_attention_generator_shape_vs_oracle():
+    """The shape the generator would run it at, reduced in channels: [B, 32, 48, 8, 8] (T cell: 48 x 24 scores over runs of
+    1024 values; W / H cells: 8 x 4), distinct W and H sizes in a second case, exact mode against the CPU oracle."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.attention3d import SeparableAttn
+    for shape in ((2, 32, 48, 8, 8), (1, 16, 6, 4, 8)):
+        torch.manual_seed(5)
+        at = SeparableAttn(shape[1], compute_dtype=torch.float32)
+        with torch.no_grad():
+            for m in at.model:
+                m.gamma.fill_(0.4)
+        sd = O.make_state({k: v.detach().clone() for k, v in at.state_dict().items()}, requires_grad=True)
+        x = torch.randn(*shape)
+        gy = torch.randn_like(x)
+        xr = x.clone().requires_grad_(True)
+        want = O.separable_attn(sd, "", xr)
+        want.backward(gy)
+        at = at.to(DEV)
+        xg = x.to(DEV).requires_grad_(True)
+        got = at(xg)
+        assert rel(got, want.detach()) < 2e-5, shape
+        got.backward(gy.to(DEV))
+        assert rel(xg.grad, xr.grad) < 1e-4, shape
+        scale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+        for name, prm in at.named_parameters():
+            if float(sd[name].grad.abs().max()) < 1e-4 * scale:
+                assert float(prm.grad.abs().max()) < 1e-3 * scale, name
+            else:
+                assert rel(prm.grad, sd[name].grad) < 2e-3, (shape, name)     # fp32 sums over 1e5 terms through three cells
+
+
+def test_generator_attention_flags_vs_oracle():
+    """Generator(self_attn=True, sep_attn=True): the reference's commented-out attention blocks (Generator.py:29,34) switched
+    on, exact mode, ch=2, T=4, B=2 against oracle.generator with the same flags: clips and parameter gradients incl. the
+    attention blocks' own."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.gen_net import Generator
+    torch.manual_seed(23)
+    ch, T, B, ncls, zd = 2, 4, 2, 3, 12
+    G = Generator(zd, 4, ncls, ch, T, compute_dtype=torch.float32, self_attn=True, sep_attn=True)
+    with torch.no_grad():
+        G.self_attn.gamma.fill_(0.5)
+        for m in G.sep_attn.model:
+            m.gamma.fill_(0.3)
+    assert "self_attn.query_conv.weight" in G.state_dict() and "sep_attn.model.2.gamma" in G.state_dict()
+    sd = O.make_state({k: v.detach().clone() for k, v in G.state_dict().items()})
+    z, cls = torch.randn(B, zd), torch.randint(0, ncls, (B,))
+    want = O.generator(sd, z, cls, ch, T, self_attn=True, sep_attn=True)
+    plain = O.generator(O.make_state({k: v.detach().clone() for k, v in G.state_dict().items()}, requires_grad=False),
+                        z, cls, ch, T)
+    assert rel(want.detach(), plain) > 1e-2            # the blocks do change the result
+    gy = torch.randn_like(want)
+    want.backward(gy)
+    G = G.to(DEV).train()
+    got = G(z.to(DEV), cls.to(DEV))
+    assert rel(got, want.detach()) < 5e-4
+    got.backward(gy.to(DEV))
+    for name in ("self_attn.gamma", "self_attn.value_conv.weight", "sep_attn.model.0.gamma", "sep_attn.model.1.query_conv.weight",
+                 "sep_attn.model.2.value_conv.weight", "conv.0.cells.1.update_gate.weight", "conv.9.cells.2.out_gate.weight",
+                 "affine_transfrom.weight"):
+        # ch=2 end-to-end fixture (see GEN_TOL): rounding is amplified ~100x, the gamma gradients are sums over the whole
+        # clip with heavy cancellation
+        assert rel(dict(G.named_parameters())[name].grad, sd[name].grad) < 5e-2, name
