@@ -93,6 +93,33 @@ extern "C" int dvd_convert(int sdt, const void* src, int ddt, void* dst, long lo
     return launch_status();
 }
 
+// uint8 clips [B][T][H][W][3] -> fp32 [B][3][T][H][W]: ((x / norm) - mean[c]) / std[c], clips with flip[b] != 0 mirrored in x.
+// (ToTensor + Normalize + RandomHorizontalFlip of Dataloader/transform/spatial_transforms.py:38-122,253-268 after the crop.)
+namespace {
+__global__ void clip_to_tensor_kernel(const unsigned char* src, const unsigned char* flip, float* dst, long long B, int T, int H,
+                                      int W, float norm, const float* ms) {
+    const long long per = (long long)3 * T * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * per) return;
+    const long long b = i / per;
+    long long e = i - b * per;
+    const int x = (int)(e % W); e /= W;
+    const int y = (int)(e % H); e /= H;
+    const int t = (int)(e % T);
+    const int c = (int)(e / T);
+    const int xs = flip[b] ? W - 1 - x : x;
+    const float v = (float)src[((((size_t)b * T + t) * H + y) * W + xs) * 3 + c];
+    dst[i] = (v / norm - ms[c]) / ms[3 + c];
+}
+}  // namespace
+extern "C" int dvd_clip_to_tensor(const unsigned char* src, const unsigned char* flip, float* dst, long long B, int T, int H, int W,
+                                  float norm_value, const float* mean_std, void* stream) {
+    if (!src || !flip || !dst || !mean_std || B <= 0 || T <= 0 || H <= 0 || W <= 0 || norm_value == 0.f) return DVD_E_ARG;
+    const long long n = B * 3 * T * H * W;
+    clip_to_tensor_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(src, flip, dst, B, T, H, W, norm_value, mean_std);
+    return launch_status();
+}
+
 extern "C" int dvd_abi_version(void) { return 4; }
 extern "C" const char* dvd_strerror(int code) {
     switch (code) {

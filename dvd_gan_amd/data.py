@@ -1,0 +1,178 @@
+"""Real-data input path: the UCF-101 JPEG-folder reader of the reference (Dataloader/datasets/ucf101.py:82-199 with the
+training transforms main.py:42-55 builds) feeding the HIP trainer.
+
+Split of work:
+  host (DataLoader workers): JSON annotation index (`make_dataset`, same records as the reference), JPEG decode, temporal
+      crop, the multi-scale crop + bilinear resize -- done with PIL exactly like the reference, so pixels are identical;
+      a clip leaves the worker as uint8 [T, S, S, 3] plus its flip flag (4x smaller than the reference's fp32 tensor over
+      PCIe);
+  device (`clips_to_device`, kernel dvd_clip_to_tensor): horizontal flip, ToTensor(norm_value) + Normalize(mean, std) and the
+      [T, S, S, 3] -> [3, T, S, S] layout change, one pass, into the fp32 [B, 3, T, S, S] batch `Trainer.train_step` takes.
+Random draws come from Python's `random` in the reference's order (temporal crop, then scale, crop position, flip), so a seeded
+run reproduces the reference's clips bit for bit (tests/test_gpu_data.py, fixture F12).
+"""
+import ctypes as C
+import json
+import math
+import os
+import random
+
+import torch
+import torch.utils.data as data
+
+from . import lib as L
+
+
+def load_value_file(path):                      # utils.py:54-58
+    with open(path, "r") as f:
+        return float(f.read().rstrip("\n\r"))
+
+
+def make_dataset(root_path, annotation_path, subset, n_samples_for_each_video=1, sample_duration=16):
+    """Dataloader/datasets/ucf101.py:82-140: one record per video (or per window) with its frame indices and class index."""
+    with open(annotation_path, "r") as f:
+        ann = json.load(f)
+    class_to_idx = {name: i for i, name in enumerate(ann["labels"])}
+    names, labels = [], []
+    for key, value in ann["database"].items():
+        if value["subset"] == subset:
+            names.append("{}/{}".format(value["annotations"]["label"], key))
+            labels.append(value["annotations"]["label"])
+    dataset = []
+    for name, label in zip(names, labels):
+        video_path = os.path.join(root_path, name)
+        if not os.path.exists(video_path):
+            continue
+        n_frames = int(load_value_file(os.path.join(video_path, "n_frames")))
+        if n_frames <= 0 or label not in class_to_idx:
+            continue
+        sample = {"video": video_path, "segment": [1, n_frames], "n_frames": n_frames, "video_id": name.split("/")[1],
+                  "label": class_to_idx[label]}
+        if n_samples_for_each_video == 1:
+            dataset.append(dict(sample, frame_indices=list(range(1, n_frames + 1))))
+        else:
+            step = (max(1, math.ceil((n_frames - 1 - sample_duration) / (n_samples_for_each_video - 1)))
+                    if n_samples_for_each_video > 1 else sample_duration)
+            for j in range(1, n_frames, step):
+                dataset.append(dict(sample, frame_indices=list(range(j, min(n_frames + 1, j + sample_duration)))))
+    return dataset, {i: n for n, i in class_to_idx.items()}
+
+
+def temporal_random_crop(frame_indices, size):
+    """Dataloader/transform/temporal_transforms.py:80-110 (loops the clip when it is shorter than `size`)."""
+    rand_end = max(0, len(frame_indices) - size - 1)
+    begin = random.randint(0, rand_end)
+    out = frame_indices[begin:min(begin + size, len(frame_indices))]
+    for index in out:
+        if len(out) >= size:
+            break
+        out.append(index)
+    return out
+
+
+class MultiScaleCrop:
+    """MultiScaleCornerCrop / MultiScaleRandomCrop of Dataloader/transform/spatial_transforms.py:271-367 (crop box + PIL
+    bilinear resize to `size`); `mode` = 'corner' | 'center' | 'random' as main.py:42-50 selects them."""
+
+    def __init__(self, scales, size, mode="corner"):
+        if mode not in ("corner", "center", "random"):
+            raise ValueError("train_crop must be 'random', 'corner' or 'center'")
+        self.scales, self.size, self.mode = scales, size, mode
+        self.positions = ["c"] if mode == "center" else ["c", "tl", "tr", "bl", "br"]
+
+    def randomize_parameters(self):
+        self.scale = self.scales[random.randint(0, len(self.scales) - 1)]
+        if self.mode == "random":
+            self.tl_x, self.tl_y = random.random(), random.random()
+        else:
+            self.crop_position = self.positions[random.randint(0, len(self.positions) - 1)]
+
+    def __call__(self, img):
+        from PIL import Image
+        w, h = img.size
+        crop = int(min(w, h) * self.scale)
+        if self.mode == "random":
+            x1, y1 = self.tl_x * (w - crop), self.tl_y * (h - crop)
+            box = (x1, y1, x1 + crop, y1 + crop)
+        else:
+            p = self.crop_position
+            if p == "c":
+                cx, cy, half = w // 2, h // 2, crop // 2
+                box = (cx - half, cy - half, cx + half, cy + half)
+            elif p == "tl":
+                box = (0, 0, crop, crop)
+            elif p == "tr":
+                box = (w - crop, 0, w, crop)
+            elif p == "bl":
+                box = (0, h - crop, crop, h)
+            else:
+                box = (w - crop, h - crop, w, h)
+        return img.crop(box).resize((self.size, self.size), Image.BILINEAR)
+
+
+def default_scales(initial_scale=1.0, n_scales=5, scale_step=0.84089641525):     # main.py:38-40, parameter.py:73-75
+    scales = [initial_scale]
+    for _ in range(1, n_scales):
+        scales.append(scales[-1] * scale_step)
+    return scales
+
+
+class UCF101(data.Dataset):
+    """Training-set view of a UCF-101 JPEG folder (`<root>/<class>/<video>/image_%05d.jpg` + `n_frames`, annotation JSON of
+    utils/ucf101_json.py).  __getitem__ -> (uint8 clip [T, S, S, 3], flip flag, class index)."""
+
+    def __init__(self, root_path, annotation_path, subset="training", n_frames=16, sample_size=64, scales=None,
+                 train_crop="corner", n_samples_for_each_video=1, sample_duration=16):
+        self.data, self.class_names = make_dataset(root_path, annotation_path, subset, n_samples_for_each_video, sample_duration)
+        self.n_frames = n_frames
+        self.crop = MultiScaleCrop(scales or default_scales(), sample_size, train_crop)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, index):
+        import numpy as np
+        from PIL import Image
+        rec = self.data[index]
+        frame_indices = temporal_random_crop(list(rec["frame_indices"]), self.n_frames)
+        self.crop.randomize_parameters()
+        flip = random.random() < 0.5                   # RandomHorizontalFlip.randomize_parameters / __call__ (:253-268)
+        frames = []
+        for i in frame_indices:                        # video_loader (:37-46): stops at the first missing frame
+            path = os.path.join(rec["video"], "image_{:05d}.jpg".format(i))
+            if not os.path.exists(path):
+                break
+            with open(path, "rb") as f, Image.open(f) as img:
+                frames.append(np.asarray(self.crop(img.convert("RGB")), dtype=np.uint8))
+        clip = torch.from_numpy(np.stack(frames, 0))
+        return clip, torch.tensor(bool(flip)), rec["label"]
+
+
+def clips_to_device(clips, flips, device, norm_value=255.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    """uint8 [B, T, S, S, 3] (host or device) + flip flags [B] -> fp32 [B, 3, T, S, S] on `device`:
+    ((x / norm_value) - mean) / std with the flagged clips mirrored (main.py:34-36,51-54 defaults: [-1, 1])."""
+    clips = clips.to(device, non_blocking=True).contiguous()
+    flips = flips.to(device=device, dtype=torch.uint8).contiguous()
+    B, T, S1, S2, ch = clips.shape
+    assert ch == 3 and clips.dtype == torch.uint8
+    out = torch.empty(B, 3, T, S1, S2, dtype=torch.float32, device=device)
+    ms = torch.tensor(list(mean) + list(std), dtype=torch.float32, device=device)
+    L.check(L.lib().dvd_clip_to_tensor(L.ptr(clips), L.ptr(flips), L.ptr(out), C.c_longlong(B), T, S1, S2,
+                                       C.c_float(norm_value), L.ptr(ms), L.stream()))
+    return out
+
+
+def make_loader(dataset, batch_size, num_workers=0, shuffle=True, device=None):
+    """DataLoader whose batches are (fp32 [B,3,T,S,S] on `device`, labels [B]) -- what Trainer.train expects."""
+    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, pin_memory=True,
+                             drop_last=True)
+
+    class _OnDevice:
+        def __len__(self):
+            return len(loader)
+
+        def __iter__(self):
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            for clips, flips, labels in loader:
+                yield clips_to_device(clips, flips, dev), labels
+    return _OnDevice()

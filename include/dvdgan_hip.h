@@ -276,6 +276,12 @@ int dvd_sepattn_backward(int dtype, const void* dy, int ldx, int C, int Cq, cons
                          const float* att, float* dO, float* dS, float* dQf, float* dKp, float* dVp, void* dqkv, int ldq,
                          int koff, int voff, float* dgamma, long long B, int T, int W, int H, int axis, void* stream);
 
+/* Real-data input (Dataloader/transform/spatial_transforms.py:38-122,253-268 after the host-side crop / resize): uint8 clips
+ * [B][T][H][W][3] -> fp32 [B][3][T][H][W] = ((x / norm_value) - mean[c]) / std[c], clips with flip[b] != 0 mirrored
+ * horizontally.  mean_std: device float[6] = mean RGB | std RGB. */
+int dvd_clip_to_tensor(const unsigned char* src, const unsigned char* flip, float* dst, long long B, int T, int H, int W,
+                       float norm_value, const float* mean_std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

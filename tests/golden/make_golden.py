@@ -37,6 +37,7 @@ def import_reference():
         tvu.save_image = lambda *a, **k: None
         tvu.make_grid = lambda x, *a, **k: x
         tv.utils = tvu
+        tv.get_image_backend = lambda: "PIL"
         sys.modules["torchvision"] = tv
         sys.modules["torchvision.utils"] = tvu
     if REF not in sys.path:
@@ -527,9 +528,70 @@ def f11_full_width(R):
     save("f11_full_width", keep)
 
 
+def f12_ucf101_reader(R):
+    """Real-data input path: a tiny synthetic UCF-101-style JPEG folder (2 classes, 3 videos of 9-14 frames, 40x30 pixels)
+    read through the reference's UCF101 dataset (Dataloader/datasets/ucf101.py) with the training transforms main.py:42-55
+    builds (multi-scale corner / random crop -> 16x16, random flip, ToTensor(255), Normalize(.5,.5)), T = 8, under seeded
+    `random`.  Stored: every file of the folder (bytes), the annotation JSON, and for a list of (index, seed, crop mode) the
+    clip tensor [3,T,16,16] + label the reference returned."""
+    import io, json, random, tempfile
+    from PIL import Image
+    sys.path.insert(0, REF)
+    from Dataloader.datasets.ucf101 import UCF101
+    from Dataloader.transform.spatial_transforms import (Compose, Normalize, MultiScaleCornerCrop, MultiScaleRandomCrop,
+                                                         RandomHorizontalFlip, ToTensor)
+    from Dataloader.transform.temporal_transforms import TemporalRandomCrop
+    from Dataloader.transform.target_transforms import ClassLabel
+    rng = np.random.RandomState(12)
+    st = {}
+    root = tempfile.mkdtemp()
+    vids = [("ApplyEyeMakeup", "v_a_g01_c01", 14, "training"), ("Archery", "v_b_g01_c02", 9, "training"),
+            ("Archery", "v_b_g02_c01", 5, "training"), ("Archery", "v_b_g03_c01", 11, "validation")]
+    files = []
+    for cls, vid, n, _ in vids:
+        d = os.path.join(root, "jpg", cls, vid)
+        os.makedirs(d)
+        base = rng.rand(30, 40, 3)
+        for i in range(1, n + 1):
+            img = np.clip(255 * (0.6 * base + 0.4 * np.sin(np.linspace(0, 3, 40))[None, :, None] * (i / n) + 0.1 * rng.rand(30, 40, 3)), 0, 255)
+            Image.fromarray(img.astype(np.uint8)).save(os.path.join(d, "image_{:05d}.jpg".format(i)), quality=90)
+        open(os.path.join(d, "n_frames"), "w").write(str(n) + "\n")
+    ann = {"labels": ["ApplyEyeMakeup", "Archery"],
+           "database": {vid: {"subset": sub, "annotations": {"label": cls}} for cls, vid, n, sub in vids}}
+    ann_path = os.path.join(root, "ucf101_01.json")
+    json.dump(ann, open(ann_path, "w"))
+    for dp, _, fns in os.walk(root):
+        for fn in sorted(fns):
+            rel = os.path.relpath(os.path.join(dp, fn), root)
+            files.append(rel)
+            st["file." + rel] = np.frombuffer(open(os.path.join(dp, fn), "rb").read(), dtype=np.uint8)
+    st["meta.files"] = np.array(files)
+    scales = [1.0]
+    for _ in range(1, 5):
+        scales.append(scales[-1] * 0.84089641525)
+    cases = []
+    for mode in ("corner", "random", "center"):
+        crop = (MultiScaleRandomCrop(scales, 16) if mode == "random" else
+                MultiScaleCornerCrop(scales, 16) if mode == "corner" else MultiScaleCornerCrop(scales, 16, crop_positions=["c"]))
+        spatial = Compose([crop, RandomHorizontalFlip(), ToTensor(255), Normalize([0.5, 0.5, 0.5], [0.5, 0.5, 0.5])])
+        ds = UCF101(os.path.join(root, "jpg"), ann_path, "training", spatial_transform=spatial,
+                    temporal_transform=TemporalRandomCrop(8), target_transform=ClassLabel())
+        assert len(ds) == 3
+        for index in range(3):
+            for seed in (1, 2, 3):
+                random.seed(100 * seed + index)
+                clip, label = ds[index]
+                tag = f"{mode}.{index}.{seed}"
+                st["out.clip." + tag], st["out.label." + tag] = npy(clip), np.array(label)
+                cases.append(tag)
+    st["meta.cases"] = np.array(cases)
+    save("f12_ucf101_reader", st)
+
+
 ALL = {"f1": f1_spectral_norm, "f2": f2_conditional_norm, "f3": f3_gresblock, "f4": f4_convgru,
        "f5": f5_attention, "f6": f6_generator, "f7": f7_discriminators, "f8": f8_helpers,
-       "f9": f9_trainer_steps, "f10": f10_config1, "f11": f11_full_width}
+       "f9": f9_trainer_steps, "f10": f10_config1, "f11": f11_full_width,
+       "f12": f12_ucf101_reader}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

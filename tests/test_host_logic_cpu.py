@@ -123,3 +123,33 @@ def test_argument_validation_messages():
     with pytest.raises(IndexError):
         tr._check_labels(torch.tensor([0, 3]))
     assert tr._check_labels(torch.tensor([0, 2])) is not None
+
+
+def test_ucf101_reader_host_side_matches_reference(tmp_path):
+    """Host half of the real-data path (index, temporal crop, PIL crop / resize, flip draw) against fixture F12 = what the
+    reference's UCF101 dataset produced; the device half (flip + normalise + layout) is emulated here with torch CPU ops."""
+    import os
+    import random
+    import numpy as np
+    from conftest import load_golden
+    from dvd_gan_amd import data as D
+    g = load_golden("f12_ucf101_reader")
+    root = str(tmp_path)
+    for rel in [str(x) for x in g["meta.files"]]:
+        path = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "wb") as f:
+            f.write(g["file." + rel].tobytes())
+    for mode in ("corner", "random", "center"):
+        ds = D.UCF101(os.path.join(root, "jpg"), os.path.join(root, "ucf101_01.json"), "training", n_frames=8, sample_size=16,
+                      train_crop=mode)
+        assert len(ds) == 3                                   # the validation video is not in the training subset
+        for tag in [str(x) for x in g["meta.cases"] if str(x).startswith(mode + ".")]:
+            _, index, seed = tag.split(".")
+            random.seed(100 * int(seed) + int(index))
+            clip, flip, label = ds[int(index)]
+            assert label == int(g["out.label." + tag])
+            if bool(flip):
+                clip = clip.flip(2)
+            got = ((clip.float().div(255) - 0.5) / 0.5).permute(3, 0, 1, 2).numpy()
+            np.testing.assert_array_equal(got, g["out.clip." + tag], err_msg=tag)
