@@ -188,13 +188,20 @@ def main():
         torch.cuda.empty_cache()
     sync()
     t0 = time.perf_counter()
+    from dvd_gan_amd import functional as Fn
     for i in range(a.steps):
         if i == a.steps - 1 and not a.no_kernel_prof:
-            lib.dvd_prof_enable(1)      # HIP events around every conv launch of the LAST timed step, recorded on the
-        losses = tr.train_step(real, labels, hidden=hidden)    # launch stream (5.4k event pairs cost ~2 % of a step, so not on all K)
+            # HIP events around every conv launch of the LAST timed step, recorded on the launch stream (5.4k event pairs cost
+            # ~2 % of a step, so not on all K).  In that step the weight-gradient kernels run on the launch stream as well
+            # instead of beside it: a kernel's duration is taken while it has the GPU to itself (the step is ~3 % slower for
+            # it, which `value` pays for once in K steps).
+            lib.dvd_prof_enable(1)
+            Fn.serialize_weight_grads(True)
+        losses = tr.train_step(real, labels, hidden=hidden)
     sync()
     dt = time.perf_counter() - t0
     lib.dvd_prof_enable(0)
+    Fn.serialize_weight_grads(False)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -222,6 +229,7 @@ def main():
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),
                 "gflop_per_launch": round(dom["gflop_per_launch"], 2), "kernel_ms_per_step": round(dom["ms"], 1),
                 "wgrad": {k: round(v, 2) if isinstance(v, float) else v for k, v in res["conv_wgrad"].items()},
+                "timing": "HIP events on the launch stream around each launch of the last timed step, kernels serialised (no concurrent weight-gradient stream) in that step",
                 "step_achieved": round(value / world * F / 1e3, 1) if F else None,
                 "step_frac": round(value / world * F / 1e3 / peak, 4) if F else None}
     if rank == 0:

@@ -470,6 +470,8 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
     constexpr int NB = BNt / 16 / NWAVE;                      // weight-tile DMAs per wave
     constexpr int HBYTES = HG * 1024, BBYTES = BNt * 64;
     // weight ring depth: NSTAGE-1 tiles in flight.  4 where LDS allows (the 256 x 128 variant runs 2 workgroups per CU)
+    // (a fourth stage for the 3 x 3 filters, whose smaller footprint leaves room for it at two workgroups per CU, measured
+    //  +0.6 %: the ring depth is not what limits the loop)
     constexpr int NSTAGE = (TM == 4 && WN == 2) ? 3 : 4;
     constexpr int EPI = NWAVE * 32 * 64 * 4;
     constexpr int LDSB = 2 * HBYTES + 1024 + NSTAGE * BBYTES > EPI ? 2 * HBYTES + 1024 + NSTAGE * BBYTES : EPI;
@@ -535,9 +537,9 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
         cob[j] = n0 + (j * NWAVE + wu) * 16 + lrow; cov[j] = cob[j] < p.Cout;
         woff[j] = ((unsigned)cob[j] * p.C + q * E16) * esz;
     }
-    // footprint of outer index oc -> halo buffer hb
-    auto dmaH = [&](int hb, int oc) __attribute__((always_inline)) {
-        const int cc_ = oc / p.kt, it_ = oc - cc_ * p.kt;
+    // footprint of the outer index (cc_, it_) -> halo buffer hb.  (The (chunk, dt) pairs are kept as running counters: an
+    // integer division per K step costs ~20 scalar instructions on the wave that is about to issue its MFMAs.)
+    auto dmaH = [&](int hb, int cc_, int it_) __attribute__((always_inline)) {
         const int dt_ = it_ - (p.kt >> 1);
         const bool ok_ = (unsigned)(tt + dt_) < (unsigned)p.T || p.kt == 1;
         const unsigned ud_ = (unsigned)(ft + dt_ - base_frame) * (unsigned)fbytes + cc_ * 64;
@@ -550,15 +552,14 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
         }
     };
     // weight tile of (chunk, tap): running iterator, two steps ahead of the multiply
-    int b_oc = oc_begin, b_tap = 0;
+    int b_cc = oc_begin / p.kt, b_it = oc_begin - b_cc * p.kt, b_tap = 0;
     auto dmaB = [&](int stg) __attribute__((always_inline)) {
-        const int cc_ = b_oc / p.kt, it_ = b_oc - cc_ * p.kt;
-        const bool cv_ = cc_ * BK + q * E16 < p.C;
-        const unsigned uw_ = (unsigned)((it_ * ntap2 + b_tap) * p.Cout) * (unsigned)p.C * esz + cc_ * 64;
+        const bool cv_ = b_cc * BK + q * E16 < p.C;
+        const unsigned uw_ = (unsigned)((b_it * ntap2 + b_tap) * p.Cout) * (unsigned)p.C * esz + b_cc * 64;
         char* bbase_ = bring + stg * BBYTES + wu * 1024;
 #pragma unroll
         for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_) ? woff[j] + uw_ : 0xffffffffu);
-        if (++b_tap == ntap2) { b_tap = 0; ++b_oc; }
+        if (++b_tap == ntap2) { b_tap = 0; if (++b_it == p.kt) { b_it = 0; ++b_cc; } }
     };
 
     f32x16 acc[TM][2];
@@ -580,7 +581,9 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
     if (nsteps > 0) {
 #define VMCNT(n) (((n) & 0xf) | (7 << 4) | (0xf << 8) | (((n) >> 4) << 14))
         constexpr int FL = NSTAGE - 2;                         // weight tiles allowed to stay in flight past tile s+1
-        dmaH(0, oc_begin);
+        int h_cc = b_cc, h_it = b_it;                          // outer index of the NEXT footprint to fetch
+        dmaH(0, h_cc, h_it);
+        if (++h_it == p.kt) { h_it = 0; ++h_cc; }
 #pragma unroll
         for (int i = 0; i < NSTAGE - 1; ++i)
             if (i < nsteps) dmaB(i);
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
             const bool issueH = m_tap == 0 && m_oc + 1 < oc_end;
             if (!late) {
                 if (issueB) dmaB(st2);                         // stage st2 was last read in step sidx-1
-                if (issueH) dmaH(hb ^ 1, m_oc + 1);
+                if (issueH) { dmaH(hb ^ 1, h_cc, h_it); if (++h_it == p.kt) { h_it = 0; ++h_cc; } }
             }
             {
                 // footprint row of this lane's sub-tile 0 for tap (iy, ix)
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
             }
             if (late) {
                 if (issueB) dmaB(st2);
-                if (issueH) dmaH(hb ^ 1, m_oc + 1);
+                if (issueH) { dmaH(hb ^ 1, h_cc, h_it); if (++h_it == p.kt) { h_it = 0; ++h_cc; } }
             }
             // In-order completion: weight tile sidx+1 has landed once at most the FL younger tiles (plus, for the
             // NSTAGE-1 steps after a footprint went out behind tile sidx+NSTAGE-1, that footprint) are outstanding.

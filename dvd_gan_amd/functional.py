@@ -24,13 +24,19 @@ from . import lib as L
 # `join_side()` (main stream waits for the side stream) must run before the gradients are read: Trainer does it after
 # every backward().  Parameters without a persistent .grad (stock optimizers with zero_grad(set_to_none=True), module
 # tests) take the autograd route unchanged.
-_SIDE = {"on": False, "stream": None}
+_SIDE = {"on": False, "stream": None, "serial": False}
 
 
 def direct_weight_grads(flag):
     """Switch the side-stream / direct-accumulation route on or off (Trainer turns it on; DVD_SIDE_WGRAD=0 vetoes)."""
     import os
     _SIDE["on"] = bool(flag) and os.environ.get("DVD_SIDE_WGRAD", "1") != "0"
+
+
+def serialize_weight_grads(flag):
+    """Measurement aid (bench.py's instrumented step): keep the direct accumulation but launch the weight-gradient kernels on
+    the CURRENT stream, so every kernel has the GPU to itself while its duration is being taken."""
+    _SIDE["serial"] = bool(flag)
 
 
 def side_stream():
@@ -71,6 +77,9 @@ class _on_side:
         self.tensors = [t for t in tensors if t is not None]
 
     def __enter__(self):
+        if _SIDE["serial"]:
+            self.cm = None
+            return torch.cuda.current_stream()
         side = side_stream()
         side.wait_stream(torch.cuda.current_stream())
         for t in self.tensors:
@@ -80,7 +89,7 @@ class _on_side:
         return side
 
     def __exit__(self, *exc):
-        return self.cm.__exit__(*exc)
+        return self.cm.__exit__(*exc) if self.cm is not None else False
 
 
 # ------------------------------------------------------------------ boundary layout

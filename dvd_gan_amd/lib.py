@@ -7,7 +7,7 @@ import torch
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdvdgan_hip.so")
+LIB_PATH = os.environ.get("DVD_LIB_PATH") or os.path.join(_HERE, "csrc", "libdvdgan_hip.so")    # (override: A/B builds)
 _lib = None
 
 
