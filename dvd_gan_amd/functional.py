@@ -24,7 +24,8 @@ from . import lib as L
 # `join_side()` (main stream waits for the side stream) must run before the gradients are read: Trainer does it after
 # every backward().  Parameters without a persistent .grad (stock optimizers with zero_grad(set_to_none=True), module
 # tests) take the autograd route unchanged.
-_SIDE = {"on": False, "stream": None, "serial": False}
+import os as _os
+_SIDE = {"on": False, "stream": None, "serial": _os.environ.get("DVD_SIDE_SERIAL") == "1"}     # env: profiling aid, see below
 
 
 def direct_weight_grads(flag):

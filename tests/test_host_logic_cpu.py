@@ -153,3 +153,22 @@ def test_ucf101_reader_host_side_matches_reference(tmp_path):
                 clip = clip.flip(2)
             got = ((clip.float().div(255) - 0.5) / 0.5).permute(3, 0, 1, 2).numpy()
             np.testing.assert_array_equal(got, g["out.clip." + tag], err_msg=tag)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher must spawn N ranks or fail loudly -- never run one GPU and print
+    n_gpus: 1 (round-1 defect).  Here no GPU is visible, so N = 2 must exit with the count in the message."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in (r.stderr + r.stdout) and "GPU(s) visible" in (r.stderr + r.stdout)
+    # launched by a launcher with a world size that contradicts --gpus: refuse as well
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -9,9 +9,14 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
 timeout 500 python bench.py > $out/bench.json 2> $out/bench.err
 tail -c 1500 $out/bench.json
-timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o st -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-prof > $out/prof.log 2>&1
+# kernel durations with every kernel alone on the GPU (weight gradients on the launch stream): the per-kernel roofline table
+DVD_SIDE_SERIAL=1 timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o st -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-prof > $out/prof.log 2>&1
 python tools/rocpd_summary.py /tmp/prof_$tag/st_results.db $out/stats.csv
 tail -1 $out/prof.log | cut -c1-160
+# the same command as it runs by default (weight gradients on the concurrent side stream: durations overlap)
+timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/profc_$tag -o st -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-prof > $out/prof_concurrent.log 2>&1
+python tools/rocpd_summary.py /tmp/profc_$tag/st_results.db $out/stats_concurrent.csv
+tail -1 $out/prof_concurrent.log | cut -c1-160
 DVD_PROF_CSV=/tmp/shapes_$tag.csv timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python tools/prof_shapes.py /tmp/shapes_$tag.csv 60 > $out/shapes.txt
 timeout 900 rocprofv3 -i tools/pmc_traffic.txt --kernel-trace -d /tmp/pmc_$tag -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-prof > $out/pmc.log 2>&1

@@ -34,7 +34,62 @@ def timed(fn, iters):
     return ts[len(ts) // 2]
 
 
+def setup(name, S, cin, hid, k, B, T, dev, dt, lib):
+    M = B * S * S
+    gx = (torch.randn(T, M, 3 * hid, device=dev) * 0.5).to(dt)
+    pur = K.PackedConv(dt, 2 * hid, hid, (k, k), dev).fill(torch.randn(2 * hid, hid, k, k, device=dev) * (0.5 / (hid * k * k) ** 0.5))
+    po = K.PackedConv(dt, hid, hid, (k, k), dev).fill(torch.randn(hid, hid, k, k, device=dev) * (0.5 / (hid * k * k) ** 0.5))
+    keep = [gx, pur, po]
+    mk = lambda: torch.empty(T, M, hid, dtype=dt, device=dev)
+    bufs = [mk() for _ in range(5)]
+    h32 = torch.empty(2, M, hid, dtype=torch.float32, device=dev)
+    ntaps = k * k
+    ns = [lib.dvd_conv_pick_nsplit(L.BF16, C.c_longlong(M), co, ci, ntaps) for co, ci in ((2 * hid, hid), (hid, hid), (hid, 2 * hid))]
+    ws = torch.empty(max(ns[0] * 2, ns[1], ns[2]) * M * hid, dtype=torch.float32, device=dev)
+    d = L.GruDesc()
+    d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.BF16, T, B, S, S, hid, k
+    d.gx_stride = M * 3 * hid
+    d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
+    d.wd_ur, d.wd_o = pur.wd.data_ptr(), po.wd.data_ptr()
+    d.h_all, d.u_all, d.r_all, d.o_all, d.hr_all = (t.data_ptr() for t in bufs)
+    d.h32, d.ws = h32.data_ptr(), ws.data_ptr()
+    dh = (torch.randn(T, M, hid, device=dev) * 0.1).to(dt)
+    dg = torch.empty(T, M, 3 * hid, dtype=dt, device=dev)
+    carry = torch.empty(M, hid, dtype=torch.float32, device=dev)
+    d.dh_out, d.dg, d.carry = dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
+    keep += bufs + [h32, ws, dh, dg, carry]
+    return d, keep
+
+
+def pairs(iters, B, T):
+    """Two layers' time loops on two streams at once vs one after the other (how much a layer wavefront could hide)."""
+    dev, dt = "cuda", torch.bfloat16
+    lib = L.lib()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for a, b in ((0, 1), (3, 4), (6, 7), (9, 10), (1, 2), (4, 5)):
+        da, ka = setup(*LAYERS[a], B, T, dev, dt, lib)
+        db, kb = setup(*LAYERS[b], B, T, dev, dt, lib)
+
+        def run(fn_name, concurrent):
+            fn = getattr(lib, fn_name)
+            cur = torch.cuda.current_stream()
+            if not concurrent:
+                st = C.c_void_p(cur.cuda_stream)
+                L.check(fn(C.byref(da), st)); L.check(fn(C.byref(db), st))
+                return
+            s1.wait_stream(cur); s2.wait_stream(cur)
+            L.check(fn(C.byref(da), C.c_void_p(s1.cuda_stream)))
+            L.check(fn(C.byref(db), C.c_void_p(s2.cuda_stream)))
+            cur.wait_stream(s1); cur.wait_stream(s2)
+        for fn_name in ("dvd_convgru_layer_forward", "dvd_convgru_layer_backward"):
+            ts = timed(lambda: run(fn_name, False), iters)
+            tc = timed(lambda: run(fn_name, True), iters)
+            print(f"{LAYERS[a][0]} + {LAYERS[b][0]} {fn_name[19:]:9s}: sequential {ts:7.2f} ms   concurrent {tc:7.2f} ms   ({100 * (1 - tc / ts):4.1f} % saved)", flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pairs":
+        return pairs(3, 64, 48)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     sel = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2] else range(len(LAYERS))
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 64

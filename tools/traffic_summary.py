@@ -23,6 +23,7 @@ out = {"source": "rocprofv3 -i tools/pmc_traffic.txt (separate passes: FETCH_SIZ
        "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB",
        "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) "
                      "reads -> read bytes = 2 x FETCH_SIZE; WRITE_SIZE uncorrected (uncalibrated)",
+       "shape": {"size": 64, "frames": 48, "batch": 64, "ch": 32, "dtype": "bf16"},      # bench.py reports `traffic` only for it
        "kernels": {}}
 for k in ("conv_igemm", "conv_wgrad", "other"):
     f, nf = agg[(k, "FETCH_SIZE")], cnt[(k, "FETCH_SIZE")]
