@@ -184,8 +184,18 @@ class Trainer(object):
     def _check_labels(self, labels):
         """Class ids index embedding tables on the device (no bounds check there): reject a label outside
         [0, n_class) while it is still on the host, like the IndexError nn.Embedding raises in the reference."""
-        if not labels.is_cuda and labels.numel() and (int(labels.min()) < 0 or int(labels.max()) >= self.n_class):
-            raise IndexError(f"class id out of range for n_class={self.n_class}: [{int(labels.min())}, {int(labels.max())}]")
+        if not labels.numel():
+            return labels
+        if labels.is_cuda:
+            # a device tensor costs a host sync to inspect: done once per distinct tensor (a loader that re-uses its
+            # label buffer, bench.py) -- labels normally arrive on the host (DataLoader, label_sample) and take the free path
+            key = (labels.data_ptr(), labels._version, labels.numel())
+            if getattr(self, "_labels_ok", None) == key:
+                return labels
+            self._labels_ok = key
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= self.n_class:
+            raise IndexError(f"class id out of range for n_class={self.n_class}: [{lo}, {hi}]")
         return labels
 
     def train_step(self, real_videos, real_labels, draws=None, hidden=None):
