@@ -196,6 +196,10 @@ class TemporalDiscriminator(_DiscBase):
 
     def _forward(self, x, class_id):
         _check_frame_size(x.shape[-2], x.shape[-1])
+        if x.shape[2] % 4:
+            # two (2,2,2) average pools: the reference floors an odd length silently (Discriminators.py:380,408); the
+            # pooled-gradient kernels here need whole windows, so say it up front instead of failing in backward
+            raise ValueError(f"TemporalDiscriminator: n_frames={x.shape[2]} must be a multiple of 4 (two temporal 2x poolings)")
         xc = Fn.ToChannelsLast.apply(x, self.compute_dtype, None)            # [B,T,h,w,8]
         c1 = self.pre_conv[0](xc, act=L.ACT_RELU)
         p2 = Fn.Pool.apply(self.pre_conv[2](c1), 2)

@@ -95,6 +95,9 @@ class Generator(nn.Module):
         super().__init__()
         if hierar_flag:
             raise NotImplementedError("hierar_flag=True is broken in the reference (Generator.py:66,109)")
+        if ch < 2 or ch % 2:
+            raise ValueError(f"ch={ch}: the ConvGRU kernels keep hidden states in 16-byte channel vectors, so the smallest "
+                             "hidden size 4*ch must be a multiple of 8 (ch even)")
         if latent_dim < 1 or latent_dim & (latent_dim - 1):
             raise ValueError(f"latent_dim={latent_dim}: the HIP convolution kernels index frames with shifts, so every "
                              "stage size (latent_dim * 2^k) must be a power of two (4 -> 64x64, 8 -> 128x128 clips)")

@@ -178,3 +178,36 @@ def test_sampling_path_matches_oracle():
     assert tr.G.training
     assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
     assert float((got.cpu() - want).abs().max()) < 2e-3
+
+
+def test_step_with_padded_channel_counts_matches_oracle():
+    """ch=6 (48 / 24 / 12 generator channels, 12..96 discriminator channels: 12 is no multiple of 8 -> zero-padded channel
+    vectors in colorize and the first discriminator stages, attention with THREE query channels), B=3 with T=8 (B does not divide T: the condition mis-ordering wraps), k_sample larger than
+    T (every frame goes to D_s, utils.py:61-62): one exact-mode hinge step against the oracle."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.train_step import Trainer
+    torch.manual_seed(31)
+    ch, T, k, B, ncls, zd = 6, 8, 11, 3, 4, 10
+    cfg = argparse.Namespace(adv_loss="hinge", z_dim=zd, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
+                             total_epoch=1, d_iters=1, batch_size=B, g_lr=5e-5, d_lr=5e-5, beta1=0.0, beta2=0.9,
+                             n_class=ncls, k_sample=k)
+    tr = Trainer([], cfg, device=torch.device("cuda", 0), compute_dtype=torch.float32)
+    sds = [O.make_state({kk: v.detach().cpu().clone() for kk, v in net.state_dict().items()})
+           for net in (tr.G, tr.D_s, tr.D_t)]
+    st = O.TrainState(*sds, ch=ch, n_frames=T, k_sample=k, n_class=ncls, z_dim=zd)
+    real = torch.rand(B, 3, T, 64, 64) * 2 - 1
+    labels = torch.randint(0, ncls, (B,))
+    draws = {"perm_real": torch.randperm(T), "z": torch.randn(B, zd), "z_class": torch.randint(0, ncls, (B,)),
+             "perm_fake": torch.randperm(T)}
+    got = [float(v.detach()) for v in tr.train_step(real, labels, draws)]
+    want = O.train_step(st, real, labels, draws["z"], draws["z_class"], draws["perm_real"], draws["perm_fake"])
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
+    with pytest.raises(IndexError):
+        tr.train_step(real, torch.full((B,), ncls), draws)          # label == n_class: rejected on the host
+
+
+def test_temporal_discriminator_rejects_frame_counts_it_cannot_pool():
+    from dvd_gan_amd.disc_nets import TemporalDiscriminator
+    D = TemporalDiscriminator(2, 3, compute_dtype=torch.float32).to(DEV)
+    with pytest.raises(ValueError, match="multiple of 4"):
+        D(torch.zeros(1, 3, 6, 32, 32, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))

@@ -118,6 +118,8 @@ def test_argument_validation_messages():
         Generator(120, 6, 4, 2, 4)
     with pytest.raises(ValueError, match="power-of-two"):
         _check_frame_size(96, 96)
+    with pytest.raises(ValueError, match="ch even"):
+        Generator(120, 4, 4, 3, 4)
     tr = Trainer.__new__(Trainer)
     tr.n_class = 3
     with pytest.raises(IndexError):
