@@ -87,9 +87,36 @@ def pairs(iters, B, T):
             print(f"{LAYERS[a][0]} + {LAYERS[b][0]} {fn_name[19:]:9s}: sequential {ts:7.2f} ms   concurrent {tc:7.2f} ms   ({100 * (1 - tc / ts):4.1f} % saved)", flush=True)
 
 
+def halves(iters, B, T):
+    """One layer at batch B on one stream vs the two halves of the batch (independent recurrences) on two streams."""
+    dev, dt = "cuda", torch.bfloat16
+    lib = L.lib()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for i in range(len(LAYERS)):
+        full, kf = setup(*LAYERS[i], B, T, dev, dt, lib)
+        ha, ka = setup(*LAYERS[i], B // 2, T, dev, dt, lib)
+        hb, kb = setup(*LAYERS[i], B // 2, T, dev, dt, lib)
+        for fn_name in ("dvd_convgru_layer_forward", "dvd_convgru_layer_backward"):
+            fn = getattr(lib, fn_name)
+
+            def one():
+                L.check(fn(C.byref(full), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+            def two():
+                cur = torch.cuda.current_stream()
+                s1.wait_stream(cur); s2.wait_stream(cur)
+                L.check(fn(C.byref(ha), C.c_void_p(s1.cuda_stream)))
+                L.check(fn(C.byref(hb), C.c_void_p(s2.cuda_stream)))
+                cur.wait_stream(s1); cur.wait_stream(s2)
+            t1, t2 = timed(one, iters), timed(two, iters)
+            print(f"{LAYERS[i][0]} {fn_name[19:]:9s}: whole batch {t1:7.2f} ms   two halves on two streams {t2:7.2f} ms   ({100 * (1 - t2 / t1):5.1f} % saved)", flush=True)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "pairs":
         return pairs(3, 64, 48)
+    if len(sys.argv) > 1 and sys.argv[1] == "halves":
+        return halves(3, 64, 48)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     sel = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2] else range(len(LAYERS))
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
