@@ -301,7 +301,7 @@ class Trainer(object):
                 real_videos, real_labels = next(data_iter)
             losses = self.train_step(real_videos, real_labels)
             if self.log_epoch and step % (self.log_epoch * steps_per_epoch) == 0:
-                vals = [float(v) for v in losses]
+                vals = [float(v.detach()) for v in losses]
                 print("Step: [%d/%d], time: %.1fs, ds_loss: %.4f, dt_loss: %.4f, g_s_loss: %.4f, g_t_loss: %.4f, lr: %.2e"
                       % (step, total_step, time.time() - t0, vals[0] + vals[1], vals[2] + vals[3], vals[4], vals[5],
                          self.g_lr_scher.get_lr()[0]))
