@@ -1023,18 +1023,22 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
 //             256 contiguous bytes (conflict-free without a swizzle) and a tap is a +64-byte immediate offset.
 // UP2: the convolution reads a nearest-x2 upsampled input (GResBlock.py:57-58): the footprint is kept in INPUT
 // coordinates (half the columns), tap ix of step pixel pk reads row ((pk + ix - pad) >> 1) + 1 of it.
-template <int WM, int KW, bool RELU, bool UP2 = false>
-__global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
-    constexpr int NTt = WM * 128, BMc = WM * 64;
+// NH: 32-channel blocks of input channels per workgroup (2 = 64 channels; 4 = 128, used with WM = 2 so that the 128-channel
+// output tile also runs as ONE 8-wave workgroup per CU and can stagger its two halves, see the main loop).
+template <int WM, int KW, bool RELU, bool UP2 = false, int NH = 2>
+__global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
+    constexpr int NWAVE = WM * NH, NTt = NWAVE * 64, BMc = WM * 64, BNc = NH * 32;
     constexpr int RSA = BMc * 2 + 64;
     constexpr int TA_BYTES = 32 * RSA;
-    constexpr int XROWS = 48, XHALF = XROWS * 64, TB_BYTES = 2 * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows
+    constexpr int XROWS = 48, XHALF = XROWS * 64, TB_BYTES = NH * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows
     constexpr int NS = 2;      // 32-pixel sub-steps per barrier (3x3: 0.72 -> 0.80 PF/s, 5x5: +3 %; three sub-steps cost occupancy)
     constexpr int SUB = TA_BYTES + TB_BYTES, STAGE = NS * SUB;
-    constexpr int EPIB = WM * 2 * 32 * 32 * 4;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE > EPIB ? 2 * STAGE : EPIB];
+    constexpr int EPIB = NWAVE * 32 * 32 * 4;
+    constexpr int REDB = NTt * 8 * 4;                            // bias partial sums
+    constexpr int LDSB = 2 * STAGE > EPIB ? (2 * STAGE > REDB ? 2 * STAGE : REDB) : (EPIB > REDB ? EPIB : REDB);
+    __shared__ __attribute__((aligned(16))) char smem[LDSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NH, wn = wave % NH;
     int bx = blockIdx.x, bz = blockIdx.z;
     if (p.xcd_remap) {
         const int gx = gridDim.x, total = gx * gridDim.z, lin = bx + gx * bz;
@@ -1046,7 +1050,7 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
     const int irow = bx / tiles;                                 // filter row index: it * kh + iy
     const int rem = bx - irow * tiles;
     const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
-    const int co0 = tco * BMc, ci0 = tci * 64;
+    const int co0 = tco * BMc, ci0 = tci * BNc;
     constexpr int pad = KW >> 1;
     const int it = irow / KW, iy = irow - it * KW;               // kh == kw
     const int dyl = iy - pad, dtl = it - (p.kt >> 1);
@@ -1077,20 +1081,21 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
     const int rra = tid / CPRA, cka = tid % CPRA;
     const int cy = co0 + cka * 8;
     const bool cyv = cy < p.Cy;
-    // x footprint loader: XROWS * 8 chunks over NTt threads
-    constexpr int NXL = (XROWS * 8 + NTt - 1) / NTt;
+    // x footprint loader: XROWS * CPX 16-byte chunks over NTt threads
+    constexpr int CPX = NH * 4;
+    constexpr int NXL = (XROWS * CPX + NTt - 1) / NTt;
     int xseg[NXL], xj[NXL], xdst[NXL];
     unsigned xcb[NXL];
     bool xcv[NXL];
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-        const int q = tid + i * NTt, row = q >> 3, c8 = q & 7;
+        const int q = tid + i * NTt, row = q / CPX, c8 = q % CPX;
         xseg[i] = row / fpr;
         xj[i] = row - xseg[i] * fpr;
         const int cx = ci0 + c8 * 8;
         xcv[i] = row < frows && cx < p.C;
         xcb[i] = (unsigned)cx * 2;
-        xdst[i] = q < XROWS * 8 ? (c8 >> 2) * XHALF + row * 64 + (c8 & 3) * 16 : -1;
+        xdst[i] = q < XROWS * CPX ? (c8 >> 2) * XHALF + row * 64 + (c8 & 3) * 16 : -1;
     }
     u32x4 ra[NS][NPA], rb[NS][NXL];
     auto gload1 = [&](int mk, u32x4 (&ra)[NPA], u32x4 (&rb)[NXL]) __attribute__((always_inline)) {
@@ -1209,16 +1214,35 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
         for (int s_ = 0; s_ < NS; ++s_) mma1(&smem[buf * STAGE + s_ * SUB]);
     };
     if (m_begin < m_end) {
+        // One 8-wave workgroup per CU: waves w and w+4 share a SIMD and would run their load-issue / MFMA / LDS-store phases in
+        // lockstep, leaving the matrix pipe idle while both issue memory operations.  The upper half of the waves therefore
+        // works one stage further ahead in registers and does its LDS stores and global loads BETWEEN the two sub-steps, while
+        // the lower half does them at the stage boundaries: 1.16 -> 1.29 PF/s (5 x 5), 0.86 -> 0.92 (3 x 3, 256-channel tile).
+        // Measured alternatives: loads / stores compiled out 1.41 / 1.58 PF/s; both halves one stage ahead (stores at the top
+        // of the stage) -1.3 %; LDS-DMA staging in a 3-stage ring (no registers, no ds_write; swizzled unpadded rows) 1.13 PF/s,
+        // 1.22 staggered: a `buffer_load ... lds` costs more issue time beside MFMAs than a register load plus its ds_write.
+        const bool late = NWAVE == 8 && NS == 2 && wave >= 4;
         gload(m_begin);
         lstore(0);
-        __syncthreads();
+        if (late) gload(m_begin + 32 * NS);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
         int buf = 0;
         for (int mk = m_begin; mk < m_end; mk += 32 * NS, buf ^= 1) {
-            gload(mk + 32 * NS);                  // past the slice: out-of-range offsets -> zeros
-            mma(buf);
-            lstore(buf ^ 1);
-            __syncthreads();
+            if (!late) {
+                gload(mk + 32 * NS);              // past the slice: out-of-range offsets -> zeros
+                mma(buf);
+                lstore(buf ^ 1);
+            } else {
+                mma1(&smem[buf * STAGE]);
+                lstore(buf ^ 1);
+                gload(mk + 2 * 32 * NS);
+                mma1(&smem[buf * STAGE + (NS - 1) * SUB]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
         }
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): the upper half still has a prefetch in flight
     }
     if (do_bias) {
         float* red = reinterpret_cast<float*>(&smem[0]);
@@ -1250,12 +1274,12 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
             const int cob = co0 + wm * 64 + a * 32 + (lane >> 5);
             const int tap = irow * KW + t;
             if (p.ws) {
-                // partial tile of this row slice: [slice][x-block][tap of the row][BMc][64], plain coalesced stores
-                float* wt = p.ws + (((size_t)bz * gridDim.x + bx) * KW + t) * (size_t)(BMc * 64) +
-                            (size_t)(wm * 64 + a * 32) * 64 + wn * 32;
+                // partial tile of this row slice: [slice][x-block][tap of the row][BMc][BNc], plain coalesced stores
+                float* wt = p.ws + (((size_t)bz * gridDim.x + bx) * KW + t) * (size_t)(BMc * BNc) +
+                            (size_t)(wm * 64 + a * 32) * BNc + wn * 32;
 #pragma unroll 1
                 for (int j = 0; j < 16; ++j)
-                    wt[(size_t)(2 * j + (lane >> 5)) * 64 + (lane & 31)] = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+                    wt[(size_t)(2 * j + (lane >> 5)) * BNc + (lane & 31)] = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
             } else if (ci < p.Cin_real) {
                 float* dst = p.dw + ci * p.s_ci + tap * p.s_tap;
 #pragma unroll 1
@@ -1270,18 +1294,18 @@ __global__ __launch_bounds__(WM * 128) void conv_wgrad_row_kernel(WgK p) {
 }
 
 // reduction of the row kernel's partial tiles: dw[co][ci][iy*KW + t] += sum over slices
-struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; };
+struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, BNc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; };
 __global__ void wgrad_row_reduce_kernel(WgRowRedK p) {
-    const int tile_elems = p.KW * p.BMc * 64;
+    const int tile_elems = p.KW * p.BMc * p.BNc;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)p.gx * tile_elems) return;
     const int bx = (int)(i / tile_elems), e = (int)(i - (long long)bx * tile_elems);
-    const int t = e / (p.BMc * 64), e2 = e - t * (p.BMc * 64);
-    const int r = e2 >> 6, c = e2 & 63;
+    const int t = e / (p.BMc * p.BNc), e2 = e - t * (p.BMc * p.BNc);
+    const int r = e2 / p.BNc, c = e2 - r * p.BNc;
     const int tiles = p.tiles_co * p.tiles_ci;
     const int iy = bx / tiles, rem = bx - iy * tiles;
     const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
-    const int co = tco * p.BMc + r, ci = tci * 64 + c;
+    const int co = tco * p.BMc + r, ci = tci * p.BNc + c;
     if (co >= p.Cout || ci >= p.Cin_real) return;
     float a = 0.f;
     for (int z = 0; z < p.nslice; ++z) a += p.ws[((size_t)z * p.gx + bx) * tile_elems + e];
@@ -1518,6 +1542,11 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         static const int force_wm = getenv("DVD_WGR_WM") ? atoi(getenv("DVD_WGR_WM")) : 0;
         ta = d->Cout <= 64 ? 1 : (w4 <= w2 ? 4 : 2); tb = 1;
         if (force_wm && ta > force_wm) ta = force_wm;
+        // 128-channel output tile, 5 taps: take 128 input channels too (one 8-wave workgroup per CU whose halves stagger their
+        // loads, like the 256-channel tile) when that pads Cin no further: 1.20 -> 1.33 PF/s on 3.1 M x 256 -> 384; with 3 taps
+        // the two 4-wave workgroups per CU of the 64-channel form stay 3 % ahead
+        static const int wide = getenv("DVD_WGR_NH4") ? atoi(getenv("DVD_WGR_NH4")) : 1;
+        if (wide && ta == 2 && d->kw == 5 && !d->up2 && (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64) tb = 2;
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
@@ -1544,7 +1573,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         // whole rounds: the workgroups run `conc` at a time (register / LDS limited); a grid a few workgroups over a
         // multiple of that pays a full extra round (20 x 103 = 2060 workgroups = 8.05 rounds of 256 -> 9 rounds)
         static const int quant = getenv("DVD_WG_QUANT") ? atoi(getenv("DVD_WG_QUANT")) : 1;
-        const long long conc = 256ll * ((mode == 1 && ta == 4) ? 1 : 2);
+        const long long conc = 256ll * ((mode == 1 && (ta == 4 || tb == 2)) ? 1 : 2);
         if (quant && base * msplit > conc) {
             const long long rounds = (base * msplit + conc / 2) / conc;           // nearest
             long long ms2 = rounds * conc / base;
@@ -1568,7 +1597,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
 extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
     WgK p; dim3 grid; int ta, tb, mode; long long msplit;
     if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
-    if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * 64;
+    if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64);
     return msplit * (long long)grid.x * (ta * 64) * (tb * 64);
 }
 
@@ -1588,17 +1617,22 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
 #define LAUNCH_ROW_UP(WM_)                                                                          \
         do { if (d->relu_in) conv_wgrad_row_kernel<WM_, 3, true, true><<<grid, WM_ * 128, 0, st>>>(p);  \
              else conv_wgrad_row_kernel<WM_, 3, false, true><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
+#define LAUNCH_ROW_W(KW_)                                                                           \
+        do { if (d->relu_in) conv_wgrad_row_kernel<2, KW_, true, false, 4><<<grid, 512, 0, st>>>(p);    \
+             else conv_wgrad_row_kernel<2, KW_, false, false, 4><<<grid, 512, 0, st>>>(p); } while (0)
         if (d->up2) { if (ta == 4) LAUNCH_ROW_UP(4); else if (ta == 2) LAUNCH_ROW_UP(2); else LAUNCH_ROW_UP(1); }
+        else if (tb == 2) { if (d->kw == 5) LAUNCH_ROW_W(5); else LAUNCH_ROW_W(3); }
         else
         if (ta == 4)      { if (d->kw == 5) LAUNCH_ROW(4, 5); else LAUNCH_ROW(4, 3); }
         else if (ta == 2) { if (d->kw == 5) LAUNCH_ROW(2, 5); else LAUNCH_ROW(2, 3); }
         else              { if (d->kw == 5) LAUNCH_ROW(1, 5); else LAUNCH_ROW(1, 3); }
 #undef LAUNCH_ROW
 #undef LAUNCH_ROW_UP
+#undef LAUNCH_ROW_W
         if (p.ws) {
-            WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, d->kw, p.Cout, p.Cin_real,
+            WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, tb * 64, d->kw, p.Cout, p.Cin_real,
                         p.s_co, p.s_ci, p.s_tap};
-            const long long n = (long long)grid.x * r.KW * r.BMc * 64;
+            const long long n = (long long)grid.x * r.KW * r.BMc * r.BNc;
             wgrad_row_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(r);
         }
         return launch_status();

@@ -56,6 +56,13 @@ CASES = [
     (3, 72, 136, (16, 16), (5, 5), False, False),    # W = 16: a 32-pixel step is two lines; 128-channel tile, ragged
     (2, 64, 200, (32, 32), (3, 3), False, True),     # 256-channel tile, 3 taps per row, ReLU on the staged input
     (2, 56, 264, (16, 64), (5, 5), False, False),    # W = 64: two segments per line; 2 x 1 tiles, ragged both ways
+    # more filter-row geometries: each tile width x filter size x line geometry, staggered 8-wave variants
+    (5, 48, 200, (8, 8), (5, 5), False, False),      # W = 8: four lines per step, 256-channel tile
+    (9, 72, 56, (8, 16), (3, 3), False, False),      # 64-channel tile, ragged slices
+    (1, 16, 136, (4, 16, 16), (3, 3, 3), False, False),  # 3-D, 256-channel tile: footprint from frame t+dt
+    (33, 24, 120, (32, 32), (5, 5), False, False),   # 128-channel tile, 64 input channels, several ragged row slices
+    (6, 128, 120, (16, 16), (5, 5), False, False),   # 128 x 128-channel tile (8 waves), 5 taps
+    (2, 256, 384, (32, 32), (3, 3), False, True),    # 128 x 128-channel tile, 3 x 2 tiles, ReLU on the staged input
 ]
 
 
@@ -121,6 +128,10 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     K.conv_wgrad(xc, gyc, dw, ks, Cout, Cin, up2=up2, relu_in=relu_in)
     assert rel(dw.cpu(), wq_.grad) < 5e-6
     assert rel(dw.cpu(), wr.grad) < (5e-6 if exact else 6e-3)
+    # fused bias gradient (column sums of dy, accumulated by the centre-row workgroups)
+    db = torch.zeros(Cout, device=dev)
+    K.conv_wgrad(xc, gyc, torch.zeros_like(dw), ks, Cout, Cin, up2=up2, relu_in=relu_in, dbias=db)
+    assert rel(db.cpu(), gyq.transpose(0, 1).reshape(Cout, -1).sum(1)) < 5e-6
     dw2 = torch.zeros_like(dw)
     K.conv_wgrad(xc, gyc, dw2, ks, Cout, Cin, up2=up2, relu_in=relu_in, msplit=1)
     # one slice = one fp32 accumulator chain over all M rows: rounding grows with the chain length (131072 rows: 6.5e-6)

@@ -30,6 +30,10 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (64, 32, 512, 256, 3, False),
     (128, 32, 128, 256, 3, False),    # 19, 20: two and four rounds of the same tiles
     (256, 32, 128, 256, 3, False),
+    (3008, 32, 256, 256, 5, False),   # 21..24: the large weight-gradient shapes (gru3.l1 / gru2.l1 h-part, 3x3 blocks)
+    (3008, 16, 512, 512, 5, False),
+    (3072, 32, 128, 128, 3, False),
+    (3072, 16, 256, 256, 3, False),
 ]
 
 
