@@ -387,12 +387,12 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
         }
         __builtin_amdgcn_s_barrier();
         int st = 0, st2 = 2;                                   // stage of tile s, stage of tile s+2
-        const bool late = WN == 4 && wu >= NWAVE / 2;
+        constexpr bool late = true;
         for (int sidx = 0; sidx < nsteps; ++sidx) {
             const bool issue = sidx + 2 < nsteps;
-            // 8-wave tiles put two waves on every SIMD: the second half issues its DMAs AFTER its MFMAs,
-            // so on each SIMD one wave's (slow to issue) LDS-DMAs sit beside its partner's MFMA burst
-            // instead of both waves stalling on DMA issue and then sharing the matrix pipe.
+            // The (slow to issue) LDS-DMAs of a step go out AFTER its MFMA block, while the matrix pipe drains, instead of in
+            // front of it where they delay the first fragment reads: +2 % on the 8 x 8 recurrent convolutions (first form:
+            // only the second half of the waves of the 8-wave tile did this), see also conv_halo_kernel.
             if (issue && !late) dma(st2);                      // stage st2 was last read in step sidx-1
             mma_swz<T, TM, RELU>(&smem[st][0], &smem[st][ABYTES], arow, brow, lane, acc);
             if (issue && late) dma(st2);
@@ -590,7 +590,10 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
         if (nsteps > FL) __builtin_amdgcn_s_waitcnt(VMCNT(FL * NB));     // footprint + tile 0 landed
         else __builtin_amdgcn_s_waitcnt(VMCNT(0));
         __builtin_amdgcn_s_barrier();
-        const bool late = WN == 4 && wu >= NWAVE / 2;
+        // The DMAs of a step go out AFTER its MFMA block (all ds_reads issued, the matrix pipe still draining): +2...7 % on the
+        // 5 x 5 shapes, +0...3 % on 3 x 3 against issuing them first.  Measured alternatives: in the middle of the block (after
+        // unit 1 / 3 / 5 of 8) -7 %; every other wave or every other workgroup late -4...-8 %.
+        constexpr bool late = true;
         int st = 0, st2 = NSTAGE - 1, hb = 0, m_oc = oc_begin, m_tap = 0, iy = 0, ix = 0;
         for (int sidx = 0; sidx < nsteps; ++sidx) {
             const bool issueB = sidx + NSTAGE - 1 < nsteps;

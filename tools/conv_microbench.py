@@ -34,6 +34,9 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (3008, 16, 512, 512, 5, False),
     (3072, 32, 128, 128, 3, False),
     (3072, 16, 256, 256, 3, False),
+    (3072, 32, 128, 256, 5, False),   # 25..27: second tier of the weight-gradient shapes
+    (3072, 16, 256, 512, 5, False),
+    (3072, 32, 256, 128, 5, False),
 ]
 
 
