@@ -1026,6 +1026,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
 //             256 contiguous bytes (conflict-free without a swizzle) and a tap is a +64-byte immediate offset.
 // UP2: the convolution reads a nearest-x2 upsampled input (GResBlock.py:57-58): the footprint is kept in INPUT
 // coordinates (half the columns), tap ix of step pixel pk reads row ((pk + ix - pad) >> 1) + 1 of it.
+// 3 x 3 filters stay near 0.9 PF/s: with three taps per row the LDS is the limit, not the staging traffic -- per stage of the
+// 256-channel tile 640 cycles of fragment reads + 624 of ds_write_b128 (13 cycles each) against 1536 MFMA cycles, 82 % busy
+// (5 taps: 59 %).  A nine-tap variant (128 x 64 channel tile, dy staged once for all three filter rows, 146 staged bytes per
+// MFMA instead of 212) was built and passed the tests: +3 % on 786 k x 256 -> 256, -2 % on 3.1 M x 128 -> 128 (its 10 fragment
+// reads per 9 MFMAs keep the LDS as busy); removed.
 // NH: 32-channel blocks of input channels per workgroup (2 = 64 channels; 4 = 128, used with WM = 2 so that the 128-channel
 // output tile also runs as ONE 8-wave workgroup per CU and can stagger its two halves, see the main loop).
 template <int WM, int KW, bool RELU, bool UP2 = false, int NH = 2>

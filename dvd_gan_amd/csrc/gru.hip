@@ -21,6 +21,28 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// acc[0..7] += sum over the ns split-K slabs of 8 floats at `off` (slab s starts s * stride floats further).  The loads of four
+// slabs are requested before the first is added: these kernels run a few hundred waves on mostly empty CUs and a loop of
+// load -> add -> load is a chain of ns L2 / HBM round trips (16 slabs: 12-19 us per launch).  The additions keep slab order.
+__device__ __forceinline__ void slab_sum8(const float* ws, int ns, size_t stride, size_t off, float (&acc)[8]) {
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {
+        float a[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load8<float>(ws + (size_t)(s + j) * stride + off, a[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += a[j][k];
+    }
+    for (; s < ns; ++s) {
+        float a[8];
+        load8<float>(ws + (size_t)s * stride + off, a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += a[k];
+    }
+}
+
 // u, r, hr for one step.  ws: [ns][M][2h] fp32 partial sums of conv(h_prev; Wh_ur) (ns may be 0).
 template <typename T>
 __global__ void gru_gates_ur_kernel(const float* ws, int ns, const T* gx, int ldg, const T* hprev, T* u, T* r, T* hr,
@@ -33,15 +55,30 @@ __global__ void gru_gates_ur_kernel(const float* ws, int ns, const T* gx, int ld
     float pu[8], pr[8], hp[8];
     load8<T>(gx + (size_t)row * ldg + c, pu);
     load8<T>(gx + (size_t)row * ldg + h + c, pr);
-    for (int s = 0; s < ns; ++s) {
-        float a[8], b[8];
-        const float* w = ws + ((size_t)s * M + row) * 2 * h;
-        load8<float>(w + c, a);
-        load8<float>(w + h + c, b);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { pu[k] += a[k]; pr[k] += b[k]; }
-    }
     if (hprev) load8<T>(hprev + (size_t)row * h + c, hp);
+    {
+        const size_t stride = (size_t)M * 2 * h, off = (size_t)row * 2 * h + c;
+        int s = 0;
+        for (; s + 4 <= ns; s += 4) {
+            float a[4][8], b[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                load8<float>(ws + (size_t)(s + j) * stride + off, a[j]);
+                load8<float>(ws + (size_t)(s + j) * stride + off + h, b[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { pu[k] += a[j][k]; pr[k] += b[j][k]; }
+        }
+        for (; s < ns; ++s) {
+            float a[8], b[8];
+            load8<float>(ws + (size_t)s * stride + off, a);
+            load8<float>(ws + (size_t)s * stride + off + h, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { pu[k] += a[k]; pr[k] += b[k]; }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         pu[k] = sigmoidf_(pu[k]);
@@ -64,12 +101,6 @@ __global__ void gru_out_kernel(const float* ws, int ns, const T* gx, int ldg, co
     const int c = (int)(i - row * cg) * 8;
     float po[8], hp[8], uu[8];
     load8<T>(gx + (size_t)row * ldg + 2 * h + c, po);
-    for (int s = 0; s < ns; ++s) {
-        float a[8];
-        load8<float>(ws + ((size_t)s * M + row) * h + c, a);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) po[k] += a[k];
-    }
     if (h32p) load8<float>(h32p + (size_t)row * h + c, hp);
     else if (hprev) load8<T>(hprev + (size_t)row * h + c, hp);
     else {
@@ -77,6 +108,7 @@ __global__ void gru_out_kernel(const float* ws, int ns, const T* gx, int ldg, co
         for (int k = 0; k < 8; ++k) hp[k] = 0.f;
     }
     load8<T>(u + (size_t)row * h + c, uu);
+    slab_sum8(ws, ns, (size_t)M * h, (size_t)row * h + c, po);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         po[k] = round_to<T>(tanhf(po[k]));
@@ -104,14 +136,10 @@ __global__ void gru_bwd_out_kernel(const T* dh_out, float* carry, const float* w
 #pragma unroll
         for (int k = 0; k < 8; ++k) dh[k] += t8[k];
     }
-    for (int s = 0; s < ns; ++s) {
-        load8<float>(ws + ((size_t)s * M + row) * h + c, t8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dh[k] += t8[k];
-    }
     load8<T>(u + off, uu);
     load8<T>(o + off, oo);
     if (hprev) load8<T>(hprev + off, hp);
+    slab_sum8(ws, ns, (size_t)M * h, off, dh);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float hpk = hprev ? hp[k] : 0.f;
@@ -137,11 +165,7 @@ __global__ void gru_bwd_r_kernel(float* carry, const float* ws, int ns, const T*
     float dhr[8], t8[8], rr[8], hp[8], cy[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) dhr[k] = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        load8<float>(ws + ((size_t)s * M + row) * h + c, t8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dhr[k] += t8[k];
-    }
+    slab_sum8(ws, ns, (size_t)M * h, off, dhr);
     if (hprev) {
         load8<T>(r + off, rr);
         load8<T>(hprev + off, hp);
