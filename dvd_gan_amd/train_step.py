@@ -223,7 +223,10 @@ class Trainer(object):
         T, k = self.n_frames, self.k_sample
         ex = self.exchange
         fg = self.frame_gen
+        draws_all = draws
         for _ in range(self.d_iters):
+            if isinstance(draws_all, (list, tuple)):              # test aid: one dict of draws per discriminator iteration
+                draws = draws_all[_]
             ids_real = draw_frame_ids(T, k, fg) if draws is None else torch.as_tensor(draws["perm_real"])[:k].sort()[0]
             real_s = sample_k_frames(real_videos, T, k, ids_real)
             z = (torch.randn(self.batch_size, self.z_dim) if draws is None else torch.as_tensor(draws["z"])).to(self.device)

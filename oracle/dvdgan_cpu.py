@@ -365,32 +365,40 @@ def snapshot_grads(st):
     return snaps
 
 
-def train_step(st, real_videos, real_labels, z, z_class, perm_real, perm_fake, rec=None):
-    """trainer.py:213-307 with d_iters=1.  real_videos: [B,3,T,H,W]; RNG draws are passed in
-    the order the reference consumes them: perm_real, z, z_class, perm_fake.
-    Returns the six loss terms [ds_real, ds_fake, dt_real, dt_fake, g_s, g_t].
+def train_step(st, real_videos, real_labels, z, z_class, perm_real, perm_fake, rec=None, d_iters=1):
+    """trainer.py:213-307.  real_videos: [B,3,T,H,W]; RNG draws are passed in the order the reference consumes them:
+    perm_real, z, z_class, perm_fake -- for d_iters > 1 (the loop of trainer.py:230) each of the four is a sequence with one
+    entry per discriminator iteration; the generator step uses the clips of the LAST iteration (trainer.py:296-297).
+    Returns the six loss terms [ds_real, ds_fake, dt_real, dt_fake, g_s, g_t] (discriminator terms of the last iteration).
     rec (test aid): a dict that receives the generator taps (`generator(..., taps=)`), the generated clips and the six
     raw discriminator outputs, for teacher-forced comparisons of single modules."""
     taps = [] if rec is not None else None
     real = real_videos.permute(0, 2, 1, 3, 4).contiguous()                      # :227
-    real_s = sample_k_frames(real, frame_ids_from_perm(perm_real, st.k))           # :233
-    fake = generator(st.G, z, z_class, st.ch, st.T, st.latent_dim, taps=taps)    # :239
-    fake_s = sample_k_frames(fake, frame_ids_from_perm(perm_fake, st.k))           # :242
-    # ---- D_s ----                                                                 :243-253
-    o_sr, o_sf = spatial_disc(st.Ds, real_s, real_labels), spatial_disc(st.Ds, fake_s.detach(), z_class)
-    ds_real = adv_loss(o_sr, True, st.adv)
-    ds_fake = adv_loss(o_sf, False, st.adv)
-    st.zero_grad()
-    (ds_real + ds_fake).backward()
-    st.ds_opt.step()
-    # ---- D_t ----                                                                 :256-269
-    real_d, fake_d = vid_downsample(real), vid_downsample(fake)
-    o_tr, o_tf = temporal_disc(st.Dt, real_d, real_labels), temporal_disc(st.Dt, fake_d.detach(), z_class)
-    dt_real = adv_loss(o_tr, True, st.adv)
-    dt_fake = adv_loss(o_tf, False, st.adv)
-    st.zero_grad()
-    (dt_real + dt_fake).backward()
-    st.dt_opt.step()
+    if d_iters == 1:
+        z, z_class, perm_real, perm_fake = [z], [z_class], [perm_real], [perm_fake]
+    for it in range(d_iters):                                                   # :230
+        if taps is not None:
+            del taps[:]
+        real_s = sample_k_frames(real, frame_ids_from_perm(perm_real[it], st.k))       # :233
+        zc = z_class[it]
+        fake = generator(st.G, z[it], zc, st.ch, st.T, st.latent_dim, taps=taps)       # :239
+        fake_s = sample_k_frames(fake, frame_ids_from_perm(perm_fake[it], st.k))       # :242
+        # ---- D_s ----                                                             :243-253
+        o_sr, o_sf = spatial_disc(st.Ds, real_s, real_labels), spatial_disc(st.Ds, fake_s.detach(), zc)
+        ds_real = adv_loss(o_sr, True, st.adv)
+        ds_fake = adv_loss(o_sf, False, st.adv)
+        st.zero_grad()
+        (ds_real + ds_fake).backward()
+        st.ds_opt.step()
+        # ---- D_t ----                                                             :256-269
+        real_d, fake_d = vid_downsample(real), vid_downsample(fake)
+        o_tr, o_tf = temporal_disc(st.Dt, real_d, real_labels), temporal_disc(st.Dt, fake_d.detach(), zc)
+        dt_real = adv_loss(o_tr, True, st.adv)
+        dt_fake = adv_loss(o_tf, False, st.adv)
+        st.zero_grad()
+        (dt_real + dt_fake).backward()
+        st.dt_opt.step()
+    z_class = zc
     # ---- G (on the UPDATED discriminators; loss uses the "real" form) ----        :296-307
     o_gs, o_gt = spatial_disc(st.Ds, fake_s, z_class), temporal_disc(st.Dt, fake_d, z_class)
     g_s = adv_loss(o_gs, True, st.adv)

@@ -363,13 +363,15 @@ def f8_helpers(R):
 
 # ----------------------------------------------------------------------------- F9 / F10
 def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr=5e-5,
-                grads_of=(), n_batches=None, synth_big=False, grad_head=None):
+                grads_of=(), n_batches=None, synth_big=False, grad_head=None, d_iters=1):
     """Drive the unmodified reference Trainer.train() (trainer.py:189-307) on CPU and
     record every RNG draw, the six loss terms per step, named gradients and parameter
     checksums at each optimizer.step().
     synth_big: every floating-point state tensor with >= synth.BIG elements and the input clips are set to the
     closed-form values of tests/golden/synth.py BEFORE the reference runs, and are not stored.
-    grad_head: store only the first `grad_head` elements (flattened) of each named gradient."""
+    grad_head: store only the first `grad_head` elements (flattened) of each named gradient.
+    d_iters > 1 (trainer.py:230): the draws of discriminator iteration i of step s are stored as in.<name>.<s>.<i>; losses,
+    gradients and checksums are those of the LAST discriminator iteration of the step (and of the generator update)."""
     import trainer as TR
     import synth
     import torch.nn as nn
@@ -378,7 +380,7 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
     cfg = argparse.Namespace(
         model="dvd-gan", adv_loss=adv_loss, imsize=64, g_num=5, z_dim=z_dim, g_chn=ch, ds_chn=ch,
         dt_chn=ch, n_frames=T, g_conv_dim=64, d_conv_dim=64, lr_schr="const", lambda_gp=10,
-        total_epoch=1 if n_batches is None else steps // n_batches, d_iters=1, g_iters=1, batch_size=B, num_workers=0, g_lr=lr, d_lr=lr,
+        total_epoch=1 if n_batches is None else steps // n_batches, d_iters=d_iters, g_iters=1, batch_size=B, num_workers=0, g_lr=lr, d_lr=lr,
         lr_decay=0.9999, beta1=0.0, beta2=0.9, pretrained_model=None, n_class=n_class,
         k_sample=k, dataset="ucf101", use_tensorboard=False, test_batch_size=1,
         image_path="/tmp/x", log_path="/tmp/x", model_save_path="/tmp/x", sample_path="/tmp/x",
@@ -447,14 +449,24 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
         torch.randperm, torch.randn, torch.randint = o_perm, o_randn, o_randint
     # draws[randn][0] is fixed_z (trainer.py:195); per step afterwards: perm, randn, randint, perm
     st["in.fixed_z"] = draws["randn"][0]
+    D = d_iters
     for s in range(steps):
-        st[f"in.perm_real.{s}"] = draws["randperm"][2 * s]
-        st[f"in.perm_fake.{s}"] = draws["randperm"][2 * s + 1]
-        st[f"in.z.{s}"] = draws["randn"][1 + s]
-        st[f"in.z_class.{s}"] = draws["randint"][s]
-        st[f"out.losses.{s}"] = np.array(losses[6 * s: 6 * s + 6], dtype=np.float64)
+        if D == 1:
+            st[f"in.perm_real.{s}"] = draws["randperm"][2 * s]
+            st[f"in.perm_fake.{s}"] = draws["randperm"][2 * s + 1]
+            st[f"in.z.{s}"] = draws["randn"][1 + s]
+            st[f"in.z_class.{s}"] = draws["randint"][s]
+        else:
+            for i in range(D):
+                st[f"in.perm_real.{s}.{i}"] = draws["randperm"][2 * (s * D + i)]
+                st[f"in.perm_fake.{s}.{i}"] = draws["randperm"][2 * (s * D + i) + 1]
+                st[f"in.z.{s}.{i}"] = draws["randn"][1 + s * D + i]
+                st[f"in.z_class.{s}.{i}"] = draws["randint"][s * D + i]
+        per = 4 * D + 2                       # calc_loss calls per step: 4 per discriminator iteration + 2
+        last = losses[per * s + 4 * (D - 1): per * s + 4 * D] + losses[per * s + 4 * D: per * (s + 1)]
+        st[f"out.losses.{s}"] = np.array(last, dtype=np.float64)
         for tag in ("Ds", "Dt", "G"):
-            g, gsum, psum = snaps[tag][s]
+            g, gsum, psum = snaps[tag][s if tag == "G" else s * D + D - 1]
             for kk, v in g.items():
                 st[f"grad.{s}.{tag}.{kk}"] = v
             keys = sorted(gsum)
@@ -469,6 +481,7 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
     st["meta.cfg"] = np.array([ch, T, k, B, n_class, steps, z_dim], dtype=np.int64)
     st["meta.lr"] = np.array(lr)
     st["meta.synth"] = np.array(int(synth_big))
+    st["meta.d_iters"] = np.array(d_iters)
     return st
 
 
@@ -526,6 +539,17 @@ def f11_full_width(R):
                      z_dim=120, lr=5e-5, grads_of=F11_NAMES, synth_big=True, grad_head=8192)
     keep = {k: v for k, v in st.items() if not (".sd1." in k and v.size >= 4096)}
     save("f11_full_width", keep)
+
+
+def f13_two_d_iters(R):
+    """d_iters = 2 (trainer.py:230): two discriminator updates per step with fresh draws, the generator forward twice in
+    train mode, the generator update on the clips of the second iteration.  ch=2, T=8, k=4, B=1, 3 classes, 2 steps, hinge."""
+    names = ("conv.0.cells.1.update_gate.weight", "conv.1.conv0.module.weight_bar", "embedding.weight",
+             "colorize.module.weight_bar", "pre_conv.0.module.weight_bar", "linear.module.weight_bar",
+             "res3d.conv1.module.weight_bar")
+    st = run_trainer(R, adv_loss="hinge", ch=2, T=8, k=4, B=1, n_class=3, steps=2, seed=160, z_dim=12, lr=2e-3,
+                     grads_of=names, d_iters=2)
+    save("f13_two_d_iters", st)
 
 
 def f12_ucf101_reader(R):
@@ -591,7 +615,7 @@ def f12_ucf101_reader(R):
 ALL = {"f1": f1_spectral_norm, "f2": f2_conditional_norm, "f3": f3_gresblock, "f4": f4_convgru,
        "f5": f5_attention, "f6": f6_generator, "f7": f7_discriminators, "f8": f8_helpers,
        "f9": f9_trainer_steps, "f10": f10_config1, "f11": f11_full_width,
-       "f12": f12_ucf101_reader}
+       "f12": f12_ucf101_reader, "f13": f13_two_d_iters}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

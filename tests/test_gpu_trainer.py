@@ -23,8 +23,8 @@ def make_trainer(g, base, adv, dtype):
     ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
     lr = float(g["meta.lr"])
     cfg = argparse.Namespace(adv_loss=adv, z_dim=z_dim, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
-                             total_epoch=1, d_iters=1, batch_size=B, g_lr=lr, d_lr=lr, beta1=0.0, beta2=0.9,
-                             n_class=n_class, k_sample=k)
+                             total_epoch=1, d_iters=int(g["meta.d_iters"]) if "meta.d_iters" in g else 1, batch_size=B,
+                             g_lr=lr, d_lr=lr, beta1=0.0, beta2=0.9, n_class=n_class, k_sample=k)
     tr = Trainer([], cfg, device=torch.device(DEV), compute_dtype=dtype)
     for net, sd in zip((tr.G, tr.D_s, tr.D_t), full_states(base)):
         net.load_state_dict({kk: torch.as_tensor(v) for kk, v in sd.items()})
@@ -204,6 +204,58 @@ def test_step_with_padded_channel_counts_matches_oracle():
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
     with pytest.raises(IndexError):
         tr.train_step(real, torch.full((B,), ncls), draws)          # label == n_class: rejected on the host
+
+
+def test_two_discriminator_iterations_golden(golden):
+    """Golden F13: the reference Trainer with d_iters = 2 (trainer.py:230), B = 1, two steps.  Exact mode: step-0 losses (last
+    discriminator iteration + generator) at the tolerance of the F9 test, later step looser (one Adam update deep), and the
+    forward-only state (BN running statistics, spectral-norm vectors: advanced 2 x 2 times) after both steps."""
+    g = golden("f13_two_d_iters")
+    tr, steps = make_trainer(g, g, "hinge", torch.float32)
+    assert tr.d_iters == 2
+    for s in range(steps):
+        draws = [{"perm_real": g[f"in.perm_real.{s}.{i}"], "z": g[f"in.z.{s}.{i}"], "z_class": g[f"in.z_class.{s}.{i}"],
+                  "perm_fake": g[f"in.perm_fake.{s}.{i}"]} for i in range(2)]
+        got = [float(v.detach()) for v in tr.train_step(torch.as_tensor(fixture_real(g, s)), torch.as_tensor(g[f"in.labels.{s}"]), draws)]
+        if s == 0:
+            np.testing.assert_allclose(got, g[f"out.losses.{s}"], rtol=2e-3, atol=2e-4, err_msg="losses step 0")
+        else:
+            np.testing.assert_allclose(got, g[f"out.losses.{s}"], rtol=1e-2, atol=2e-2, err_msg=f"losses step {s}")
+    for tag, net in (("G", tr.G), ("Ds", tr.D_s), ("Dt", tr.D_t)):
+        sd = net.state_dict()
+        for k, v in sub(g, tag + ".sd1").items():
+            if k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
+                assert float((sd[k].double().cpu() - torch.as_tensor(v).double()).norm() / (np.linalg.norm(v) + 1e-30)) < 5e-2, k
+
+
+def test_two_discriminator_iterations_per_step_match_oracle():
+    """d_iters = 2 (trainer.py:230): two discriminator updates with fresh z / labels / frame draws each, generator forward in
+    train mode both times (BN running statistics and spectral-norm vectors advance twice), then the generator step on the clips
+    of the LAST iteration.  B = 1: the smallest batch (statistics over the T frames of one clip).  Two steps, exact mode."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.train_step import Trainer
+    torch.manual_seed(41)
+    ch, T, k, B, ncls, zd = 2, 8, 4, 1, 3, 12
+    cfg = argparse.Namespace(adv_loss="hinge", z_dim=zd, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
+                             total_epoch=1, d_iters=2, batch_size=B, g_lr=5e-5, d_lr=5e-5, beta1=0.0, beta2=0.9,
+                             n_class=ncls, k_sample=k)
+    tr = Trainer([], cfg, device=torch.device("cuda", 0), compute_dtype=torch.float32)
+    sds = [O.make_state({kk: v.detach().cpu().clone() for kk, v in net.state_dict().items()})
+           for net in (tr.G, tr.D_s, tr.D_t)]
+    st = O.TrainState(*sds, ch=ch, n_frames=T, k_sample=k, n_class=ncls, z_dim=zd)
+    for step in range(2):
+        real = torch.rand(B, 3, T, 64, 64) * 2 - 1
+        labels = torch.randint(0, ncls, (B,))
+        draws = [{"perm_real": torch.randperm(T), "z": torch.randn(B, zd), "z_class": torch.randint(0, ncls, (B,)),
+                  "perm_fake": torch.randperm(T)} for _ in range(2)]
+        got = [float(v.detach()) for v in tr.train_step(real, labels, draws)]
+        want = O.train_step(st, real, labels, [d["z"] for d in draws], [d["z_class"] for d in draws],
+                            [d["perm_real"] for d in draws], [d["perm_fake"] for d in draws], d_iters=2)
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
+    # the generator state that only moves in forward passes advanced 2 x 2 times on both sides
+    sd = tr.G.state_dict()
+    for key in ("conv.1.CBNorm1.bn.running_mean", "conv.1.CBNorm2.bn.running_var", "colorize.module.weight_u"):
+        assert float((sd[key].cpu() - st.G[key].detach()).abs().max()) < 2e-4, key
 
 
 def test_temporal_discriminator_rejects_frame_counts_it_cannot_pool():

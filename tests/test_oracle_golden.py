@@ -254,6 +254,32 @@ def test_f10_config1_plumbing(golden):
     _run_steps(g, g, "hinge")
 
 
+def test_f13_two_discriminator_iterations(golden):
+    """trainer.py:230 with d_iters = 2, run by the real reference: the oracle's loop consumes the recorded draws of both
+    iterations; losses (last iteration + generator), generator checksums, named gradients and the final states are compared."""
+    g = golden("f13_two_d_iters")
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    D = int(g["meta.d_iters"])
+    assert D == 2
+    lr = float(g["meta.lr"])
+    sds = full_states(g)
+    st = O.TrainState(O.make_state(sds[0]), O.make_state(sds[1]), O.make_state(sds[2]), ch=ch, n_frames=T, k_sample=k,
+                      n_class=n_class, z_dim=z_dim, adv="hinge", g_lr=lr, d_lr=lr)
+    for s in range(steps):
+        losses = O.train_step(st, t(fixture_real(g, s)), t(g[f"in.labels.{s}"]),
+                              [t(g[f"in.z.{s}.{i}"]) for i in range(D)], [t(g[f"in.z_class.{s}.{i}"]) for i in range(D)],
+                              [g[f"in.perm_real.{s}.{i}"] for i in range(D)], [g[f"in.perm_fake.{s}.{i}"] for i in range(D)],
+                              d_iters=D)
+        np.testing.assert_allclose(losses, g[f"out.losses.{s}"], rtol=2e-4, atol=2e-5, err_msg=f"losses step {s}")
+        keys = [str(x) for x in g["meta.psum_keys.G"]]
+        got = np.array([float(st.G[kk].double().abs().sum()) for kk in keys])
+        np.testing.assert_allclose(got, g[f"out.psum.{s}.G"], rtol=5e-5, err_msg=f"G psum step {s}")
+    for kk, v in sub(g, "grad.1.G").items():
+        close(st.G[kk].grad, v, 2e-3, 1e-6, what="G grad " + kk)
+    for tag, sd in (("G", st.G), ("Ds", st.Ds), ("Dt", st.Dt)):
+        check_state(sd, sub(g, tag + ".sd1"), 1e-3)
+
+
 # ------------------------------------------------------------------ F11: the benchmark's real channel widths
 def test_f11_full_width_step(golden):
     """The oracle against ONE step of the real reference at ch=32, T=48, 64x64, 101 classes, k=8, B=2 (BASELINE
