@@ -43,7 +43,7 @@ template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) { return re
 struct ConvK {
     const char* in; const char* w; const float* bias; const char* res; const char* mask;
     char* out; float* ws;
-    int M, C, ldi, Cout, ldo, ldres, ldmask;
+    int M, C, ldi, Cout, ldo, ldres, ldmask, res_up2;
     int T, H, W, logH, logW, Hin, Win;
     int kt, kh, kw, kchunks, nk, nsplit, tilesN;
     int up2, relu_in, act, out_f32;
@@ -222,7 +222,12 @@ __device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, in
     }
     if (p.res) {
         float rv[8];
-        load8<T>(reinterpret_cast<const T*>(p.res) + (size_t)row * p.ldres + col, rv);
+        int rrow = row;
+        if (p.res_up2) {            // residual kept at H/2 x W/2: nearest x2 while reading
+            const int x = row & (p.W - 1), y = (row >> p.logW) & (p.H - 1), f = row >> (p.logW + p.logH);
+            rrow = (f << (p.logW + p.logH - 2)) + ((y >> 1) << (p.logW - 1)) + (x >> 1);
+        }
+        load8<T>(reinterpret_cast<const T*>(p.res) + (size_t)rrow * p.ldres + col, rv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += rv[k];
     }
@@ -1442,6 +1447,8 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     p.in = (const char*)d->in; p.w = (const char*)d->w; p.bias = d->bias; p.res = (const char*)d->res;
     p.mask = (const char*)d->mask; p.out = (char*)d->out; p.ws = d->ws;
     p.M = (int)M; p.C = d->C; p.ldi = d->ldi; p.Cout = d->Cout; p.ldo = d->ldo; p.ldres = d->ldres; p.ldmask = d->ldmask;
+    p.res_up2 = d->res && d->res_up2;
+    if (p.res_up2 && (d->H < 2 || d->W < 2)) return DVD_E_SHAPE;
     p.T = d->T; p.H = d->H; p.W = d->W; p.logH = logH; p.logW = logW;
     p.Hin = d->up2 ? d->H / 2 : d->H; p.Win = d->up2 ? d->W / 2 : d->W;
     p.kt = d->kt; p.kh = d->kh; p.kw = d->kw;

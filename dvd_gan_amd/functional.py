@@ -162,10 +162,13 @@ class Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b, res, spec):
         pk = spec.pack
+        # a residual at half the output size is read through a nearest x2 upsample (the generator's 1x1 shortcut runs before
+        # its upsample: GResBlock.py:72-73 commute exactly)
+        ru = res is not None and res.shape[-2] * 2 == K._grid(x, spec.ksize, spec.up2)[3]
         y = K.conv_forward(x, pk.wf, spec.ksize, spec.cout, bias=b, res=res, act=spec.act, up2=spec.up2,
-                           relu_in=spec.relu_in)
+                           relu_in=spec.relu_in, res_up2=ru)
         ctx.spec, ctx.pk, ctx.sigma = spec, pk, spec.sigma
-        ctx.has_res = res is not None
+        ctx.has_res, ctx.res_up2 = res is not None, ru
         ctx.params = (w, b)                      # the Parameter objects themselves (their .grad buffers)
         ctx.save_for_backward(x, w, y if spec.act != L.ACT_NONE else None)
         return y
@@ -210,7 +213,10 @@ class Conv(Function):
                 dw = G
         elif ctx.needs_input_grad[2]:
             db = K.colsum(dy, spec.cout)
-        return dx, dw, db, (dy if ctx.has_res else None), None
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = K.pool(dy, 1, scale=1.0) if ctx.res_up2 else dy          # transpose of nearest x2: 2 x 2 sums
+        return dx, dw, db, dres, None
 
 
 class Pool(Function):

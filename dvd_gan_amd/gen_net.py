@@ -18,6 +18,10 @@ from . import lib as L
 from .sn_layers import ConditionalNorm, ConvParams, SpectralNormConv, clear_spectral_norm, prefetch_spectral_norm
 
 
+import os as _os
+_SC_LOWRES = _os.environ.get("DVD_SC_LOWRES", "1") != "0"      # A/B aid: 0 = shortcut conv on the upsampled grid (the reference's order)
+
+
 class ConvGRUCell(nn.Module):
     """Parameter holder with the reference keys {reset,update,out}_gate.{weight,bias} (ConvGRU.py:16-26)."""
 
@@ -78,7 +82,9 @@ class GResBlock(nn.Module):
         a1 = self.CBNorm1(x, cond, samp, relu=True)
         c0 = self.conv0(a1, up2=up)
         a2 = self.CBNorm2(c0, cond, samp, relu=True)
-        skip = self.conv_sc(x, up2=up)
+        # shortcut (GResBlock.py:71-73: upsample, then the 1x1 conv): a 1x1 conv commutes with a nearest upsample value for
+        # value, so it runs on the SMALL grid (a quarter of the rows) and conv1's epilogue reads it through the upsample
+        skip = self.conv_sc(x, up2=up and not _SC_LOWRES)
         return self.conv1(a2, res=skip)
 
 

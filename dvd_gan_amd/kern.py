@@ -101,7 +101,7 @@ def _grid(x, ksize, up2):
 
 
 def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L.ACT_NONE, up2=False,
-                 relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None):
+                 relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None, res_up2=False):
     """Direct (nsplit=1) or split-K convolution.  `wpack`: [ntaps][cout][Cp] tensor.  Returns the
     output tensor [F,(T,)H,W,cout_pad] (direct) or the fp32 slabs [nsplit, M, cout] (split-K)."""
     k = _ksize3(ksize)
@@ -129,7 +129,7 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
         out = alloc(shape, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d.out, d.ldo = out.data_ptr(), out.shape[-1]
     if res is not None:
-        d.res, d.ldres = res.data_ptr(), res.shape[-1]
+        d.res, d.ldres, d.res_up2 = res.data_ptr(), res.shape[-1], int(res_up2)
     if mask is not None:
         d.mask, d.ldmask = mask.data_ptr(), mask.shape[-1]
     L.check(L.lib().dvd_conv_forward(C.byref(d), L.stream()))

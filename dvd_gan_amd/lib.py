@@ -16,7 +16,7 @@ class ConvDesc(C.Structure):
                 ("C", C.c_int), ("ldi", C.c_int), ("Cout", C.c_int), ("ldo", C.c_int),
                 ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("up2", C.c_int), ("relu_in", C.c_int),
                 ("nsplit", C.c_int), ("act", C.c_int), ("out_f32", C.c_int), ("ldres", C.c_int),
-                ("ldmask", C.c_int),
+                ("ldmask", C.c_int), ("res_up2", C.c_int),
                 ("inp", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
                 ("mask", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p)]
 
@@ -47,7 +47,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def check(code):

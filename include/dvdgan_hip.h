@@ -51,7 +51,7 @@ const char* dvd_strerror(int code);
  *   Module/Discriminators.py:186-206 (GBlock), :335-366 (Res3dBlock), :221-226,:376-382 (stems),
  *   :94-96 (q/k/v 1x1), and -- run on the flipped/transposed pack -- their backward-data passes.
  * Also fuses: ReLU on the input (GResBlock.py:52,62 / Discriminators.py:186,192), nearest x2
- * upsample of the input (GResBlock.py:55,72), bias, residual add (GResBlock.py:80), ReLU/tanh
+ * upsample of the input (GResBlock.py:55,72) or of the residual, bias, residual add (GResBlock.py:80), ReLU/tanh
  * on the output (Generator.py:113-115), ReLU-mask of a backward-data result.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -66,6 +66,9 @@ typedef struct {
     int act;                   /* DVD_ACT_* (direct epilogue only)                              */
     int out_f32;               /* direct epilogue stores fp32 instead of `dtype`                */
     int ldres, ldmask;         /* row strides of res / mask                                     */
+    int res_up2;               /* 1: res is stored at H/2 x W/2 ([frames*T][H/2][W/2][ldres]) and read through a
+                                  nearest x2 upsample -- the 1x1 shortcut of GResBlock.py:72-73 commutes with the
+                                  upsample, so it runs on the small grid and is expanded here                  */
     const void* in;            /* [rows_in][ldi]                                                */
     const void* w;             /* packed [ntaps][Cout][C] (see dvd_pack_conv_weight)            */
     const float* bias;         /* [Cout] or NULL                                                */

@@ -143,6 +143,30 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     assert rel(dw2.cpu(), wq_.grad) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 16, 40, (16, 16), (3, 3)), (2, 8, 24, (4, 8, 8), (3, 3, 3)), (5, 24, 8, (32, 32), (1, 1))])
+def test_residual_read_through_nearest_upsample(shape, dtype):
+    """res_up2: the residual operand lives on the H/2 x W/2 grid and is expanded (nearest x2) in the epilogue --
+    out = conv(x) + b + upsample(res)."""
+    from dvd_gan_amd import kern as K
+    F_, Cin, Cout, sp, ks = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(F_, Cin, *sp, generator=g)
+    w = torch.randn(Cout, Cin, *ks, generator=g) / (Cin * ks[-1] * ks[-2]) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    half = sp[:-2] + (sp[-2] // 2, sp[-1] // 2)
+    res = torch.randn(F_, Cout, *half, generator=g)
+    exact = dtype == torch.float32
+    xq, wq, rq = (x, w, res) if exact else (bf(x), bf(w), bf(res))
+    up = F.interpolate(rq, scale_factor=(1, 2, 2) if len(sp) == 3 else 2)
+    want = ref_conv(xq, wq, b) + up
+    dev = "cuda"
+    pk = K.PackedConv(dtype, Cout, Cin, ks, dev).fill(w.to(dev))
+    y = K.conv_forward(K.to_cl(x.to(dev), dtype), pk.wf, ks, Cout, bias=b.to(dev), res=K.to_cl(res.to(dev), dtype),
+                       res_up2=True, out_f32=True)
+    assert rel(K.from_cl(y, Cout).cpu(), want) < 2e-6
+
+
 def test_bad_shapes_raise():
     from dvd_gan_amd import kern as K
     x = torch.zeros(1, 6, 8, 8, device="cuda")          # H=6 is not a power of two
