@@ -2,7 +2,8 @@
 """bench.py -- clips/s for one full G + D_s + D_t training step (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: re-executes itself under
-                                                               torch.distributed.run, one rank per GPU, RCCL)
+                                                               torch.distributed.run, one rank per GPU, RCCL;
+                                                               defaults: N = 1, K = 10, W = 3 -- about a minute incl. cpu_baseline)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1], per GPU): UCF-101-shaped synthetic clips, T=48, 64x64,
@@ -47,8 +48,8 @@ PEAK_BF16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: dense bf1
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default 64; at --size 128 the largest that fits)")
     ap.add_argument("--ch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=48)
