@@ -491,7 +491,8 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
         const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rr = nwg & 7;
         bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
     }
-    const int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    if (p.nmajor) { const int tilesM = gridDim.x / p.tilesN; nt = bid / tilesM; mt = bid - nt * tilesM; }
     const int n0 = nt * BNt;
     // tile -> (frame, patch origin)
     const int pw = p.W >> 4, ppf = pw * (p.H / PH);
@@ -1484,6 +1485,11 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
         static const int nmaj = getenv("DVD_CONV_NMAJOR") ? atoi(getenv("DVD_CONV_NMAJOR")) : 1;
         p.nmajor = nmaj && !halo && wb > inb && wb > (4u << 20);      // weights beyond one L2
+        // halo kernel: with several N tiles and weights well beyond one L2, a run of workgroups that shares the weight tile
+        // (and streams the activations once per N tile) misses less than one that shares the footprint and cycles through
+        // all the weights: 1272 -> 1355 TF/s on 786 k x 256 -> 1536 (19.7 MB of weights); neutral from 5 MiB, -1.5 % at 4.9 MB
+        static const long long nmaj_mb = getenv("DVD_CONV_NMAJOR_MB") ? atoll(getenv("DVD_CONV_NMAJOR_MB")) : 5;
+        if (nmaj && halo && p.tilesN > 1 && wb > ((size_t)nmaj_mb << 20)) p.nmajor = 1;
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;
