@@ -1490,6 +1490,7 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         // all the weights: 1272 -> 1355 TF/s on 786 k x 256 -> 1536 (19.7 MB of weights); neutral from 5 MiB, -1.5 % at 4.9 MB
         static const long long nmaj_mb = getenv("DVD_CONV_NMAJOR_MB") ? atoll(getenv("DVD_CONV_NMAJOR_MB")) : 5;
         if (nmaj && halo && p.tilesN > 1 && wb > ((size_t)nmaj_mb << 20)) p.nmajor = 1;
+        if (nmaj && halo && p.tilesN >= 6 && wb > (2u << 20)) p.nmajor = 1;      // 3.1 M x 128 -> 768 (4.9 MB, 6 N tiles): +2 %
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;

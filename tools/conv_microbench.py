@@ -37,6 +37,8 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (3072, 32, 128, 256, 5, False),   # 25..27: second tier of the weight-gradient shapes
     (3072, 16, 256, 512, 5, False),
     (3072, 32, 256, 128, 5, False),
+    (3072, 32, 128, 768, 5, False),   # 28: gru3.l1 x-part (short K, wide N)
+    (3072, 32, 768, 128, 5, False),   # 29: its backward-data
 ]
 
 
