@@ -11,6 +11,7 @@ import sys
 pmc_dir, out_path, note = sys.argv[1], sys.argv[2], sys.argv[3]
 agg = collections.defaultdict(float)
 cnt = collections.Counter()
+per = collections.defaultdict(lambda: [0.0, 0.0, 0])        # kernel name -> [fetch KiB, write KiB, launches]
 for path in sorted(glob.glob(f"{pmc_dir}/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(path)):
         kn = r["Kernel_Name"]
@@ -18,6 +19,12 @@ for path in sorted(glob.glob(f"{pmc_dir}/**/*counter_collection.csv", recursive=
         k = "conv_igemm" if ("conv_igemm" in kn or "conv_halo" in kn) else "conv_wgrad" if "conv_wgrad" in kn else "other"
         agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
+        short = kn.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        e = per[short]
+        if r["Counter_Name"] == "FETCH_SIZE":
+            e[0] += float(r["Counter_Value"]); e[2] += 1
+        elif r["Counter_Name"] == "WRITE_SIZE":
+            e[1] += float(r["Counter_Value"])
 out = {"source": "rocprofv3 -i tools/pmc_traffic.txt (separate passes: FETCH_SIZE, then WRITE_SIZE) --kernel-trace -- python "
                  "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-prof; config C2, B=64, bf16; " + note,
        "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB",
@@ -34,5 +41,8 @@ for k in ("conv_igemm", "conv_wgrad", "other"):
                          "write_kib_per_launch": round(w / nw, 1),
                          "hbm_bytes_per_launch_corrected": int((2 * f / nf + w / nw) * 1024),
                          "hbm_gb_per_step_corrected": round((2 * f + w) * 1024 / 1e9, 1)}
+top = sorted(per.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1]))[:16]
+out["by_kernel_gb_per_step"] = [{"kernel": k[:90], "launches": v[2], "read_gb": round(2 * v[0] * 1024 / 1e9, 1),
+                                 "write_gb": round(v[1] * 1024 / 1e9, 1)} for k, v in top]
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
