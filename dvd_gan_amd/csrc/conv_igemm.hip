@@ -1309,9 +1309,25 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
 
 // reduction of the row kernel's partial tiles: dw[co][ci][iy*KW + t] += sum over slices
 struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, BNc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; };
+// sum over the slices of four consecutive partial-tile elements (16-byte loads, four slices requested before the first addition;
+// slice order kept): the reduce kernels stream the whole workspace once and were running at 2.5 TB/s with scalar loads
+__device__ __forceinline__ f32x4 slice_sum4(const float* ws, int nslice, size_t stride, size_t off) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= nslice; z += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(ws + (size_t)(z + j) * stride + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a += v[j];
+    }
+    for (; z < nslice; ++z) a += *reinterpret_cast<const f32x4*>(ws + (size_t)z * stride + off);
+    return a;
+}
+
 __global__ void wgrad_row_reduce_kernel(WgRowRedK p) {
     const int tile_elems = p.KW * p.BMc * p.BNc;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // 4 consecutive in-channels per thread
     if (i >= (long long)p.gx * tile_elems) return;
     const int bx = (int)(i / tile_elems), e = (int)(i - (long long)bx * tile_elems);
     const int t = e / (p.BMc * p.BNc), e2 = e - t * (p.BMc * p.BNc);
@@ -1321,16 +1337,18 @@ __global__ void wgrad_row_reduce_kernel(WgRowRedK p) {
     const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
     const int co = tco * p.BMc + r, ci = tci * p.BNc + c;
     if (co >= p.Cout || ci >= p.Cin_real) return;
-    float a = 0.f;
-    for (int z = 0; z < p.nslice; ++z) a += p.ws[((size_t)z * p.gx + bx) * tile_elems + e];
-    p.dw[co * p.s_co + ci * p.s_ci + (iy * p.KW + t) * p.s_tap] += a;
+    const f32x4 a = slice_sum4(p.ws, p.nslice, (size_t)p.gx * tile_elems, (size_t)bx * tile_elems + e);
+    float* d = p.dw + co * p.s_co + ci * p.s_ci + (iy * p.KW + t) * p.s_tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ci + j < p.Cin_real) d[j * p.s_ci] += a[j];
 }
 
 // Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
 struct WgRedK { const float* ws; float* dw; int nslice, gx, gx_per_tap, tiles_ci, BMc, BNc, Cout, Cin_real; long long s_co, s_ci, s_tap; };
 __global__ void wgrad_reduce_kernel(WgRedK p) {
     const int tile_elems = p.BMc * p.BNc;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= (long long)p.gx * tile_elems) return;
     const int bx = (int)(i / tile_elems), e = (int)(i - (long long)bx * tile_elems);
     const int r = e / p.BNc, c = e - r * p.BNc;
@@ -1340,9 +1358,11 @@ __global__ void wgrad_reduce_kernel(WgRedK p) {
     const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
     const int co = tco * p.BMc + r, ci = tci * p.BNc + c;
     if (co >= p.Cout || ci >= p.Cin_real) return;
-    float a = 0.f;
-    for (int z = 0; z < p.nslice; ++z) a += p.ws[((size_t)z * p.gx + bx) * tile_elems + e];
-    p.dw[co * p.s_co + ci * p.s_ci + tap * p.s_tap] += a;
+    const f32x4 a = slice_sum4(p.ws, p.nslice, (size_t)p.gx * tile_elems, (size_t)bx * tile_elems + e);
+    float* d = p.dw + co * p.s_co + ci * p.s_ci + tap * p.s_tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ci + j < p.Cin_real) d[j * p.s_ci] += a[j];
 }
 
 // ============================================================================ weight packing
@@ -1655,7 +1675,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
             WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, tb * 64, d->kw, p.Cout, p.Cin_real,
                         p.s_co, p.s_ci, p.s_tap};
             const long long n = (long long)grid.x * r.KW * r.BMc * r.BNc;
-            wgrad_row_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(r);
+            wgrad_row_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
         }
         return launch_status();
     }
@@ -1668,7 +1688,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
         WgRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co * p.tiles_ci, p.tiles_ci, ta * 64, tb * 64, p.Cout,
                  p.Cin_real, p.s_co, p.s_ci, p.s_tap};
         const long long n = (long long)grid.x * r.BMc * r.BNc;
-        wgrad_reduce_kernel<<<cdiv(n, 256), 256, 0, st>>>(r);
+        wgrad_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
     }
     return launch_status();
 }
