@@ -12,12 +12,15 @@ typedef unsigned short bf16_t;   // raw storage
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // a real register vector (a struct here ends up in scratch)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even, NaN kept quiet: the hardware conversion (v_cvt_pk_bf16_f32, one instruction per PAIR of values).
+// The former bit-twiddling form cost five VALU operations and -- through its NaN test -- a lane-divergent branch per element.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two values -> one 32-bit word (lo in bits 0..15)
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
 
 template <typename T> struct ElemTraits;
@@ -55,10 +58,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 }
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
     u32x4 a;
-    a.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    a.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    a.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-    a.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    a.x = pack2_bf16(v[0], v[1]); a.y = pack2_bf16(v[2], v[3]); a.z = pack2_bf16(v[4], v[5]); a.w = pack2_bf16(v[6], v[7]);
     *reinterpret_cast<u32x4*>(p) = a;
 }
 
@@ -81,6 +81,15 @@ __device__ __forceinline__ float wave_max(float v) {
 // value a T-typed store would keep (bf16 rounding; identity for fp32)
 template <typename T> __device__ __forceinline__ float round_to(float v) { return v; }
 template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// Gate non-linearities of the ConvGRU (ConvGRU.py:47-51).  Exact mode (fp32 storage): libm expf / tanhf and an IEEE divide.
+// bf16 mode: the result is rounded to 8 mantissa bits anyway, so the hardware exponential and reciprocal (about 1e-6
+// relative) replace ~50 VALU instructions per element, two lane-divergent branches of tanhf included, by ~6; the fused gate
+// epilogues of the large recurrent convolutions were VALU-bound on them.
+template <typename T> __device__ __forceinline__ float gate_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+template <> __device__ __forceinline__ float gate_sigmoid<bf16_t>(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+template <typename T> __device__ __forceinline__ float gate_tanh(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ float gate_tanh<bf16_t>(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 // Internal (not part of the public ABI): ConvGRU gate math fused into the convolution epilogue, used
 // by gru.hip when the recurrent conv needs no split-K.  mode 1: [u|r] conv, mode 2: out-gate conv (forward);

@@ -115,142 +115,325 @@ __device__ __forceinline__ void mma_swz(const char* At, const char* Bt, int arow
     }
 }
 
-// Epilogue for 8 consecutive output columns of one row (values read from the wave's LDS staging area).
-template <typename T>
-__device__ __forceinline__ void conv_store8(const ConvK& p, const float* src, int row, int col, int z) {
-    float v[8];
+// ---------------------------------------------------------------------------- batched epilogue
+// The epilogue used to be a chain of dependent round trips: per 32-row sub-tile four rounds of (load the gate / residual
+// operands of 8 rows -> wait -> math -> store), each behind lane-divergent branches at whose joins hipcc waits vmcnt(0),
+// with the bias read element by element in every round: 16 serialized L2 / HBM latencies per wave, ~14 us of a launch
+// that hides nothing behind them (all workgroups of a one-round launch reach their epilogue together).  Here every
+// operand goes through a buffer descriptor, so validity is an out-of-range offset instead of a branch (loads return
+// zeros, stores are dropped; an absent optional operand is an EMPTY descriptor), the operands of all four rounds of a
+// sub-tile are requested before the first is used, and the bias is read once per wave.
+constexpr unsigned kOOB = 0x80000000u;            // offsets at / above 2 GiB are out of range for every descriptor built here
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, long long row0, unsigned ld_bytes, long long rows) {
+    const unsigned long long bytes = base ? (unsigned long long)rows * ld_bytes : 0ull;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (size_t)row0 * ld_bytes), 0,
+                                             bytes > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned)bytes, 0x00020000);
+}
+template <typename T> struct Raw8;                // 8 elements as they sit in memory
+template <> struct Raw8<bf16_t> { u32x4 a; };
+template <> struct Raw8<float> { u32x4 a, b; };
+template <typename T> __device__ __forceinline__ Raw8<T> bld8(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ Raw8<bf16_t> bld8<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    Raw8<bf16_t> v; v.a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); return v;
+}
+template <> __device__ __forceinline__ Raw8<float> bld8<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    Raw8<float> v;
+    v.a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    v.b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0);
+    return v;
+}
+__device__ __forceinline__ void unpack8(const Raw8<bf16_t>& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.a.x << 16); v[1] = __uint_as_float(r.a.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.a.y << 16); v[3] = __uint_as_float(r.a.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.a.z << 16); v[5] = __uint_as_float(r.a.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.a.w << 16); v[7] = __uint_as_float(r.a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack8(const Raw8<float>& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.a.x); v[1] = __uint_as_float(r.a.y); v[2] = __uint_as_float(r.a.z); v[3] = __uint_as_float(r.a.w);
+    v[4] = __uint_as_float(r.b.x); v[5] = __uint_as_float(r.b.y); v[6] = __uint_as_float(r.b.z); v[7] = __uint_as_float(r.b.w);
+}
+template <typename T> __device__ __forceinline__ void bst8(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[8]);
+template <> __device__ __forceinline__ void bst8<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[8]) {
+    u32x4 a;
+    a.x = pack2_bf16(v[0], v[1]); a.y = pack2_bf16(v[2], v[3]); a.z = pack2_bf16(v[4], v[5]); a.w = pack2_bf16(v[6], v[7]);
+    __builtin_amdgcn_raw_buffer_store_b128(a, r, off, 0, 0);
+}
+template <> __device__ __forceinline__ void bst8<float>(__amdgpu_buffer_rsrc_t r, unsigned off, const float (&v)[8]) {
+    u32x4 a = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    u32x4 b = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+    __builtin_amdgcn_raw_buffer_store_b128(a, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(b, r, off + 16, 0, 0);
+}
+
+// Epilogue of one wave: TM sub-tiles of 32 rows x 64 columns = R = 4*TM rounds of 8 rows x 64 columns (8 columns per lane).
+// The rounds run as a software pipeline: the operands of round i + D are requested before round i is computed (D + 1
+// register slots, static after unrolling; D per epilogue kind so that the 256 x 128 tile stays within 128 VGPRs beside its
+// 128 accumulator registers, i.e. two workgroups per CU).  stage(tm) moves sub-tile tm's accumulators into the wave's
+// LDS block before its first round.
+template <int R, int D, class Stage, class Load, class Compute>
+__device__ __forceinline__ void epi_run(Stage stage, Load load, Compute compute) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = src[k];
+    for (int i = 0; i < D && i < R; ++i) load(i);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if ((i & 3) == 0) stage(i >> 2);
+        if (i + D < R) load(i + D);
+        compute(i);
+        if ((i & 3) == 3) __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// `ep`: the wave's LDS staging block (32 x 64 floats); col: first of this lane's 8 output columns; row0: first row every
+// row of this workgroup's tile is relative to (the buffer descriptors start there, offsets stay 32-bit); relrow(tm, j): this
+// lane's row of round j of sub-tile tm, relative to row0, or a negative number when it lies past M.
+template <typename T, int TM, class RelRow>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][2], float* ep, int lane, int col, int z,
+                                              long long row0, RelRow relrow) {
+    constexpr unsigned esz = sizeof(T);
+    constexpr int R = 4 * TM;
+    constexpr bool kB = sizeof(T) == 2;           // bf16: deeper pipelines fit
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const bool colv = col < p.Cout;
+    const long long rows = (long long)p.M - row0;
+    auto stage = [&](int tm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes landed
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto staged = [&](int i, float (&v)[8]) __attribute__((always_inline)) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ep + ((i & 3) * 8 + erow) * 64 + ecol);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(ep + ((i & 3) * 8 + erow) * 64 + ecol + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    };
+    auto rrow = [&](int i) __attribute__((always_inline)) -> int { return relrow(i >> 2, i & 3); };
+    // byte offset of (row, column c) in a tensor with `ld` elements of `eb` bytes per row; kOOB when the row is past M or
+    // `ok` is false
+    auto offs = [&](int rr, unsigned ld, unsigned eb, int c, bool ok) __attribute__((always_inline)) -> unsigned {
+        return (rr >= 0 && ok) ? (unsigned)rr * (ld * eb) + (unsigned)c * eb : kOOB;
+    };
+    const int mode = p.g.mode;
+    if (mode == 1) {                // [u|r] = sigmoid(acc + gx);  hr = h_prev * r        (ConvGRU.py:47-49)
+        constexpr int D = kB ? 3 : 1;
+        const int h = p.g.h;
+        const bool isr = col >= h;
+        const int c2 = isr ? col - h : col;
+        const auto rgx = epi_rsrc(p.g.gx, row0, p.g.ldg * esz, rows), rhp = epi_rsrc(p.g.hprev, row0, h * esz, rows);
+        const auto ru = epi_rsrc(p.g.u, row0, h * esz, rows), rr_ = epi_rsrc(p.g.r, row0, h * esz, rows);
+        const auto rhr = epi_rsrc(p.g.hr, row0, h * esz, rows);
+        Raw8<T> gxv[D + 1], hpv[D + 1];
+        epi_run<R, D>(stage,
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                gxv[i % (D + 1)] = bld8<T>(rgx, offs(rr, p.g.ldg, esz, col, colv));
+                hpv[i % (D + 1)] = bld8<T>(rhp, offs(rr, h, esz, c2, colv && isr));
+            },
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                float v[8], g[8], hp[8];
+                staged(i, v); unpack8(gxv[i % (D + 1)], g); unpack8(hpv[i % (D + 1)], hp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = gate_sigmoid<T>(v[k] + g[k]);
+                    const float rk = round_to<T>(v[k]);          // the stored r is the r the cell uses
+                    hp[k] *= rk;
+                    v[k] = isr ? rk : v[k];
+                }
+                bst8<T>(ru, offs(rr, h, esz, c2, colv && !isr), v);
+                bst8<T>(rr_, offs(rr, h, esz, c2, colv && isr), v);
+                bst8<T>(rhr, offs(rr, h, esz, c2, colv && isr), hp);
+            });
+        return;
+    }
+    if (mode == 2) {                // o = tanh(acc + gx_o);  h = h_prev (1 - u) + o u          (ConvGRU.py:50-52)
+        constexpr int D = 1;
+        const int h = p.g.h;
+        const bool c32 = p.g.h32p != nullptr;
+        const auto rgx = epi_rsrc(p.g.gx, row0, p.g.ldg * esz, rows), ru = epi_rsrc(p.g.u_in, row0, h * esz, rows);
+        const auto rhp = epi_rsrc(c32 ? nullptr : p.g.hprev, row0, h * esz, rows), rh32 = epi_rsrc(p.g.h32p, row0, h * 4, rows);
+        const auto ro = epi_rsrc(p.g.o, row0, h * esz, rows), rhn = epi_rsrc(p.g.hn, row0, h * esz, rows);
+        const auto rn32 = epi_rsrc(p.g.h32n, row0, h * 4, rows);
+        Raw8<T> gxv[D + 1], uv[D + 1], hpv[D + 1];
+        Raw8<float> h32v[D + 1];
+        epi_run<R, D>(stage,
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                gxv[i % (D + 1)] = bld8<T>(rgx, offs(rr, p.g.ldg, esz, 2 * h + col, colv));
+                uv[i % (D + 1)] = bld8<T>(ru, offs(rr, h, esz, col, colv));
+                hpv[i % (D + 1)] = bld8<T>(rhp, offs(rr, h, esz, col, colv));
+                h32v[i % (D + 1)] = bld8<float>(rh32, offs(rr, h, 4, col, colv));
+            },
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                float v[8], g[8], uu[8], hp[8], hq[8];
+                staged(i, v); unpack8(gxv[i % (D + 1)], g); unpack8(uv[i % (D + 1)], uu);
+                unpack8(hpv[i % (D + 1)], hp); unpack8(h32v[i % (D + 1)], hq);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float hk = c32 ? hq[k] : hp[k];
+                    v[k] = round_to<T>(gate_tanh<T>(v[k] + g[k]));
+                    hp[k] = hk * (1.f - uu[k]) + v[k] * uu[k];
+                }
+                bst8<T>(ro, offs(rr, h, esz, col, colv), v);
+                bst8<T>(rhn, offs(rr, h, esz, col, colv), hp);
+                bst8<float>(rn32, offs(rr, h, 4, col, colv), hp);
+            });
+        return;
+    }
+    if (mode == 3) {                // BPTT: acc = d(h*r);  carry += acc*r;  d(pre_r) = acc*h_prev*r(1-r)   (gru.hip gru_bwd_r)
+        constexpr int D = kB ? 2 : 1;
+        const int h = p.g.h;
+        const auto rr_ = epi_rsrc(p.g.r, row0, h * esz, rows), rhp = epi_rsrc(p.g.hprev, row0, h * esz, rows);
+        const auto rcy = epi_rsrc(p.g.h32n, row0, h * 4, rows), rdg = epi_rsrc(p.g.o, row0, p.g.ldg * esz, rows);
+        Raw8<T> rv[D + 1], hpv[D + 1];
+        Raw8<float> cyv[D + 1];
+        epi_run<R, D>(stage,
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                rv[i % (D + 1)] = bld8<T>(rr_, offs(rr, h, esz, col, colv));
+                hpv[i % (D + 1)] = bld8<T>(rhp, offs(rr, h, esz, col, colv));
+                cyv[i % (D + 1)] = bld8<float>(rcy, offs(rr, h, 4, col, colv));
+            },
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                float v[8], r8[8], hp[8], cy[8];
+                staged(i, v); unpack8(rv[i % (D + 1)], r8); unpack8(hpv[i % (D + 1)], hp); unpack8(cyv[i % (D + 1)], cy);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { cy[k] += v[k] * r8[k]; v[k] = v[k] * hp[k] * r8[k] * (1.f - r8[k]); }
+                bst8<float>(rcy, offs(rr, h, 4, col, colv), cy);
+                bst8<T>(rdg, offs(rr, p.g.ldg, esz, h + col, colv), v);
+            });
+        return;
+    }
+    if (mode == 5) {                // BPTT: mode 4 followed by the first half of the NEXT step to process (gru_bwd_out):
+        constexpr int D = 1;        // dh = carry + acc + dh_out;  d(pre_o), d(pre_u) of that step;  carry = dh (1 - u)
+        const int h = p.g.h;
+        const auto rcy = epi_rsrc(p.g.h32n, row0, h * 4, rows), rdh = epi_rsrc(p.g.gx, row0, h * esz, rows);
+        const auto ru = epi_rsrc(p.g.u_in, row0, h * esz, rows), rog = epi_rsrc(p.g.hr, row0, h * esz, rows);
+        const auto rhp = epi_rsrc(p.g.hprev, row0, h * esz, rows), rdg = epi_rsrc(p.g.o, row0, p.g.ldg * esz, rows);
+        Raw8<float> cyv[D + 1];
+        Raw8<T> dhv[D + 1], uv[D + 1], ov[D + 1], hpv[D + 1];
+        epi_run<R, D>(stage,
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                const unsigned o = offs(rr, h, esz, col, colv);
+                cyv[i % (D + 1)] = bld8<float>(rcy, offs(rr, h, 4, col, colv));
+                dhv[i % (D + 1)] = bld8<T>(rdh, o); uv[i % (D + 1)] = bld8<T>(ru, o);
+                ov[i % (D + 1)] = bld8<T>(rog, o); hpv[i % (D + 1)] = bld8<T>(rhp, o);
+            },
+            [&](int i) __attribute__((always_inline)) {
+                const int rr = rrow(i);
+                float v[8], dh[8], t8[8], uu[8], oo[8], hp[8], dpu[8];
+                staged(i, v); unpack8(cyv[i % (D + 1)], dh); unpack8(dhv[i % (D + 1)], t8); unpack8(uv[i % (D + 1)], uu);
+                unpack8(ov[i % (D + 1)], oo); unpack8(hpv[i % (D + 1)], hp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float d = (dh[k] + t8[k]) + v[k];
+                    v[k] = d * uu[k] * (1.f - oo[k] * oo[k]);                 // d(pre_o)
+                    dpu[k] = d * (oo[k] - hp[k]) * uu[k] * (1.f - uu[k]);
+                    dh[k] = d * (1.f - uu[k]);
+                }
+                bst8<float>(rcy, offs(rr, h, 4, col, colv), dh);
+                bst8<T>(rdg, offs(rr, p.g.ldg, esz, col, colv), dpu);
+                bst8<T>(rdg, offs(rr, p.g.ldg, esz, 2 * h + col, colv), v);
+            });
+        return;
+    }
+    if (mode == 4) {                // BPTT: carry += acc  (dh contribution of the [u|r] backward-data conv)
+        constexpr int D = 3;
+        const int h = p.g.h;
+        const auto rcy = epi_rsrc(p.g.h32n, row0, h * 4, rows);
+        Raw8<float> cyv[D + 1];
+        epi_run<R, D>(stage,
+            [&](int i) __attribute__((always_inline)) { cyv[i % (D + 1)] = bld8<float>(rcy, offs(rrow(i), h, 4, col, colv)); },
+            [&](int i) __attribute__((always_inline)) {
+                float v[8], cy[8];
+                staged(i, v); unpack8(cyv[i % (D + 1)], cy);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cy[k] += v[k];
+                bst8<float>(rcy, offs(rrow(i), h, 4, col, colv), cy);
+            });
+        return;
+    }
+    if (p.ws) {                     // raw split-K partial sums [z][M][Cout]
+        if (!(p.Cout & 7)) {
+            const auto rws = epi_rsrc(p.ws, (long long)z * p.M + row0, p.Cout * 4, rows);
+            epi_run<R, 0>(stage, [&](int) __attribute__((always_inline)) {},
+                [&](int i) __attribute__((always_inline)) {
+                    float v[8];
+                    staged(i, v);
+                    bst8<float>(rws, offs(rrow(i), p.Cout, 4, col, colv), v);
+                });
+        } else {                    // ragged channel count: element stores (tm unrolled: a runtime index into acc parks it in scratch)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                stage(tm);
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = relrow(tm, j);
+                    if (rr >= 0 && colv) {
+                        float* dst = p.ws + ((size_t)z * p.M + row0 + rr) * p.Cout + col;
+                        const float* src = ep + (j * 8 + erow) * 64 + ecol;
+                        for (int k = 0; k < min(8, p.Cout - col); ++k) dst[k] = src[k];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+    // direct epilogue: bias, residual (optionally through a nearest x2 upsample), activation, ReLU mask of a backward-data result
+    constexpr int D = kB ? 3 : 1;
     const int nvalid = min(8, p.Cout - col);
-    if (p.g.mode == 1) {            // [u|r] = sigmoid(acc + gx);  hr = h_prev * r        (ConvGRU.py:47-49)
-        const int h = p.g.h;
-        float gxv[8];
-        load8<T>(reinterpret_cast<const T*>(p.g.gx) + (size_t)row * p.g.ldg + col, gxv);
+    float bias8[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 1.f / (1.f + expf(-(v[k] + gxv[k])));
-        if (col < h) {
-            store8<T>(reinterpret_cast<T*>(p.g.u) + (size_t)row * h + col, v);
-        } else {
-            const size_t o = (size_t)row * h + (col - h);
-            float hp[8];
-            load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
+    for (int k = 0; k < 8; ++k) bias8[k] = (p.bias && k < nvalid) ? p.bias[col + k] : 0.f;
+    const bool has_mask = p.mask != nullptr;
+    // the residual of a res_up2 conv lives on the half-size grid; its descriptor starts at the tile's first frame there
+    const long long res_row0 = p.res_up2 ? ((row0 >> (p.logW + p.logH)) << (p.logW + p.logH - 2)) : row0;
+    const auto rres = epi_rsrc(p.res, res_row0, p.ldres * esz, (p.res_up2 ? (long long)(p.M >> 2) : (long long)p.M) - res_row0);
+    const auto rmask = epi_rsrc(p.mask, row0, p.ldmask * esz, rows);
+    const auto rout = epi_rsrc(p.out, row0, p.ldo * (p.out_f32 ? 4u : esz), rows);
+    Raw8<T> resv[D + 1], mv[D + 1];
+    epi_run<R, D>(stage,
+        [&](int i) __attribute__((always_inline)) {
+            int rr = rrow(i);
+            mv[i % (D + 1)] = bld8<T>(rmask, offs(rr, p.ldmask, esz, col, colv));
+            if (p.res_up2 && rr >= 0) {            // residual kept at H/2 x W/2: nearest x2 while reading
+                const int row = (int)row0 + rr;
+                const int x = row & (p.W - 1), y = (row >> p.logW) & (p.H - 1), f = row >> (p.logW + p.logH);
+                rr = (f << (p.logW + p.logH - 2)) + ((y >> 1) << (p.logW - 1)) + (x >> 1) - (int)res_row0;
+            }
+            resv[i % (D + 1)] = bld8<T>(rres, offs(rr, p.ldres, esz, col, colv));
+        },
+        [&](int i) __attribute__((always_inline)) {
+            const int rr = rrow(i);
+            float v[8], rv[8], m8[8];
+            staged(i, v); unpack8(resv[i % (D + 1)], rv); unpack8(mv[i % (D + 1)], m8);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { v[k] = round_to<T>(v[k]); hp[k] *= v[k]; }
-            store8<T>(reinterpret_cast<T*>(p.g.r) + o, v);
-            store8<T>(reinterpret_cast<T*>(p.g.hr) + o, hp);
-        }
-        return;
-    }
-    if (p.g.mode == 2) {            // o = tanh(acc + gx_o);  h = h_prev (1 - u) + o u          (ConvGRU.py:50-52)
-        const int h = p.g.h;
-        const size_t o = (size_t)row * h + col;
-        float gxv[8], hp[8], uu[8];
-        load8<T>(reinterpret_cast<const T*>(p.g.gx) + (size_t)row * p.g.ldg + 2 * h + col, gxv);
-        if (p.g.h32p) load8<float>(p.g.h32p + o, hp);
-        else load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
-        load8<T>(reinterpret_cast<const T*>(p.g.u_in) + o, uu);
+            for (int k = 0; k < 8; ++k) v[k] = (v[k] + bias8[k]) + rv[k];
+            if (p.act == DVD_ACT_RELU) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] = round_to<T>(tanhf(v[k] + gxv[k]));
-            hp[k] = hp[k] * (1.f - uu[k]) + v[k] * uu[k];
-        }
-        store8<T>(reinterpret_cast<T*>(p.g.o) + o, v);
-        store8<T>(reinterpret_cast<T*>(p.g.hn) + o, hp);
-        if (p.g.h32n) store8<float>(p.g.h32n + o, hp);
-        return;
-    }
-    if (p.g.mode == 3) {            // BPTT: acc = d(h*r);  carry += acc*r;  d(pre_r) = acc*h_prev*r(1-r)   (gru.hip gru_bwd_r)
-        const int h = p.g.h;
-        const size_t o = (size_t)row * h + col;
-        float rr[8], hp[8], cy[8];
-        load8<T>(reinterpret_cast<const T*>(p.g.r) + o, rr);
-        load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
-        load8<float>(p.g.h32n + o, cy);
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            } else if (p.act == DVD_ACT_TANH) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { cy[k] += v[k] * rr[k]; v[k] = v[k] * hp[k] * rr[k] * (1.f - rr[k]); }
-        store8<float>(p.g.h32n + o, cy);
-        store8<T>(reinterpret_cast<T*>(p.g.o) + (size_t)row * p.g.ldg + h + col, v);
-        return;
-    }
-    if (p.g.mode == 5) {            // BPTT: mode 4 followed by the first half of the NEXT step to process (gru_bwd_out):
-        const int h = p.g.h;        // dh = carry + acc + dh_out;  d(pre_o), d(pre_u) of that step;  carry = dh (1 - u)
-        const size_t o = (size_t)row * h + col;
-        float dh[8], t8[8], uu[8], oo[8], hp[8], dpu[8];
-        load8<float>(p.g.h32n + o, dh);
-        if (p.g.gx) {
-            load8<T>(reinterpret_cast<const T*>(p.g.gx) + o, t8);
+                for (int k = 0; k < 8; ++k) v[k] = gate_tanh<T>(v[k]);
+            } else if (p.act == DVD_ACT_SIGMOID) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dh[k] += t8[k];
-        }
-        load8<T>(reinterpret_cast<const T*>(p.g.u_in) + o, uu);
-        load8<T>(reinterpret_cast<const T*>(p.g.hr) + o, oo);
-        if (p.g.hprev) load8<T>(reinterpret_cast<const T*>(p.g.hprev) + o, hp);
+                for (int k = 0; k < 8; ++k) v[k] = gate_sigmoid<T>(v[k]);
+            }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float d = dh[k] + v[k], hpk = p.g.hprev ? hp[k] : 0.f;
-            v[k] = d * uu[k] * (1.f - oo[k] * oo[k]);                 // d(pre_o)
-            dpu[k] = d * (oo[k] - hpk) * uu[k] * (1.f - uu[k]);
-            dh[k] = d * (1.f - uu[k]);
-        }
-        store8<float>(p.g.h32n + o, dh);
-        store8<T>(reinterpret_cast<T*>(p.g.o) + (size_t)row * p.g.ldg + col, dpu);
-        store8<T>(reinterpret_cast<T*>(p.g.o) + (size_t)row * p.g.ldg + 2 * h + col, v);
-        return;
-    }
-    if (p.g.mode == 4) {            // BPTT: carry += acc  (dh contribution of the [u|r] backward-data conv)
-        const size_t o = (size_t)row * p.g.h + col;
-        float cy[8];
-        load8<float>(p.g.h32n + o, cy);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cy[k] += v[k];
-        store8<float>(p.g.h32n + o, cy);
-        return;
-    }
-    if (p.ws) {                                                    // raw split-K partial sums
-        float* dst = p.ws + ((size_t)z * p.M + row) * p.Cout + col;
-        if (nvalid == 8 && !(p.Cout & 3)) {
-            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-            for (int k = 0; k < nvalid; ++k) dst[k] = v[k];
-        }
-        return;
-    }
-    if (p.bias) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += (k < nvalid) ? p.bias[col + k] : 0.f;
-    }
-    if (p.res) {
-        float rv[8];
-        int rrow = row;
-        if (p.res_up2) {            // residual kept at H/2 x W/2: nearest x2 while reading
-            const int x = row & (p.W - 1), y = (row >> p.logW) & (p.H - 1), f = row >> (p.logW + p.logH);
-            rrow = (f << (p.logW + p.logH - 2)) + ((y >> 1) << (p.logW - 1)) + (x >> 1);
-        }
-        load8<T>(reinterpret_cast<const T*>(p.res) + (size_t)rrow * p.ldres + col, rv);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += rv[k];
-    }
-    if (p.act == DVD_ACT_RELU) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-    } else if (p.act == DVD_ACT_TANH) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
-    } else if (p.act == DVD_ACT_SIGMOID) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 1.f / (1.f + __expf(-v[k]));
-    }
-    if (p.mask) {
-        float mv[8];
-        load8<T>(reinterpret_cast<const T*>(p.mask) + (size_t)row * p.ldmask + col, mv);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = mv[k] > 0.f ? v[k] : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (k < nvalid) ? v[k] : 0.f;  // padded channels stay exactly zero
-    if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo + col, v);
-    else store8<T>(reinterpret_cast<T*>(p.out) + (size_t)row * p.ldo + col, v);
+            for (int k = 0; k < 8; ++k) {
+                v[k] = (has_mask && !(m8[k] > 0.f)) ? 0.f : v[k];
+                v[k] = (k < nvalid) ? v[k] : 0.f;               // padded channels stay exactly zero
+            }
+            if (p.out_f32) bst8<float>(rout, offs(rr, p.ldo, 4, col, colv), v);
+            else bst8<T>(rout, offs(rr, p.ldo, esz, col, colv), v);
+        });
 }
 
 // Workgroup = 2 x 2 waves, wave tile = (TM*32) x 64  =>  block tile BM = TM*64 rows x 128 columns.
@@ -416,24 +599,10 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     // 6x slower) and turns the global stores into coalesced 16/32-byte vectors.
     float* ep = reinterpret_cast<float*>(&smem[0][0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes landed
-        __builtin_amdgcn_wave_barrier();
-        const int rbase = m0 + wm * (TM * 32) + tm * 32;
-        const int col = n0 + wn * 64 + ecol;
-        for (int j = 0; j < 4; ++j) {
-            const int row = rbase + j * 8 + erow;
-            if (row < p.M && col < p.Cout)
-                conv_store8<T>(p, ep + (j * 8 + erow) * 64 + ecol, row, col, z);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (long long)m0, [&](int tm, int j) __attribute__((always_inline)) {
+        const int rr = wm * (TM * 32) + tm * 32 + j * 8 + erow;
+        return m0 + rr < p.M ? rr : -1;
+    });
 }
 
 // ============================================================================ forward, halo-staged
@@ -701,25 +870,11 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
 
     float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
-    const int frame_row0 = ft * (p.H * p.W);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int col = n0 + wn * 64 + ecol;
-        for (int j = 0; j < 4; ++j) {
-            const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;      // pixel of the patch, row-major 16 wide
-            const int row = frame_row0 + (y0 + (pi >> 4)) * p.W + x0 + (pi & 15);
-            if (col < p.Cout)
-                conv_store8<T>(p, ep + (j * 8 + erow) * 64 + ecol, row, col, z);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    const long long frame_row0 = (long long)ft * (p.H * p.W);
+    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, frame_row0, [&](int tm, int j) __attribute__((always_inline)) {
+        const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;          // pixel of the patch, row-major 16 wide
+        return (y0 + (pi >> 4)) * p.W + x0 + (pi & 15);
+    });
 }
 
 // ============================================================================ backward-weight

@@ -19,7 +19,6 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // acc[0..7] += sum over the ns split-K slabs of 8 floats at `off` (slab s starts s * stride floats further).  The loads of four
 // slabs are requested before the first is added: these kernels run a few hundred waves on mostly empty CUs and a loop of
@@ -81,8 +80,8 @@ __global__ void gru_gates_ur_kernel(const float* ws, int ns, const T* gx, int ld
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        pu[k] = sigmoidf_(pu[k]);
-        pr[k] = round_to<T>(sigmoidf_(pr[k]));       // the stored r is the r the cell uses
+        pu[k] = gate_sigmoid<T>(pu[k]);
+        pr[k] = round_to<T>(gate_sigmoid<T>(pr[k]));       // the stored r is the r the cell uses
         hp[k] = hprev ? hp[k] * pr[k] : 0.f;
     }
     store8<T>(u + (size_t)row * h + c, pu);
@@ -111,7 +110,7 @@ __global__ void gru_out_kernel(const float* ws, int ns, const T* gx, int ldg, co
     slab_sum8(ws, ns, (size_t)M * h, (size_t)row * h + c, po);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        po[k] = round_to<T>(tanhf(po[k]));
+        po[k] = round_to<T>(gate_tanh<T>(po[k]));
         hp[k] = hp[k] * (1.f - uu[k]) + po[k] * uu[k];
     }
     store8<T>(o + (size_t)row * h + c, po);

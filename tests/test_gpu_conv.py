@@ -173,3 +173,21 @@ def test_bad_shapes_raise():
     pk = K.PackedConv(torch.float32, 8, 8, (3, 3), "cuda")
     with pytest.raises(RuntimeError):
         K.conv_forward(x, pk.wf, (3, 3), 8)
+
+
+def test_f32_to_bf16_is_round_to_nearest_even():
+    """The kernels round with the hardware conversion (v_cvt_pk_bf16_f32): bit-equal to torch's RNE cast on random bit
+    patterns, ties, denormals, the overflow boundary and infinities; NaN stays NaN."""
+    from dvd_gan_amd import kern as K
+    g = torch.Generator().manual_seed(3)
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 << 16,), generator=g, dtype=torch.int64).to(torch.int32)
+    special = torch.tensor([0x00000000, 0x80000000, 0x3f808000, 0x3f818000, 0x3f807fff, 0x3f808001, 0x00000001, 0x00008000,
+                            0x00018000, 0x007fffff, 0x7f7f7fff, 0x7f7f8000, 0x7f7fffff, 0x7f800000, 0xff800000, 0x7fc00000,
+                            0x7f800001], dtype=torch.int64).to(torch.int32)
+    x = torch.cat([bits, special]).view(torch.float32)
+    x = torch.cat([x, torch.zeros((-x.numel()) % 8)])
+    got = K.convert(x.cuda(), torch.bfloat16).cpu()
+    want = x.to(torch.bfloat16)
+    nan = torch.isnan(want.float())
+    assert bool((torch.isnan(got.float()) == nan).all())
+    assert torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan])
