@@ -16,8 +16,8 @@ Other shapes: --size 128 --n-class 600 (configs[3]; the batch defaults to the la
 Extra objects on the JSON line:
   roofline      dominant kernel family (conv_halo / conv_igemm bf16: forward + backward-data launches) --
                 algorithmic FLOPs of its launches / their summed durations, measured with HIP
-                events recorded on the launch stream around every launch of the last timed step
-                (--no-kernel-prof switches them off); also the whole-step figure (F = 8148.5 GFLOP/clip).
+                events recorded on the launch stream around every launch of ONE EXTRA step run after the timed region
+                (not part of `value`; --no-kernel-prof switches it off); also the whole-step figure (F = 8148.5 GFLOP/clip).
                 `traffic`: HBM bytes per launch from the committed rocprofv3 PMC passes of THIS shape, else null.
   cpu_baseline  the CPU oracle (oracle/dvdgan_cpu.py, a port of the reference step pinned on reference fixtures)
                 timed on the host: 1 warm-up + 2 timed steps, same shape, B=2, 16 threads (host core count alongside).
@@ -159,6 +159,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and len(candidates) > 1:
+        # Data parallel: a rank that ran out of memory inside a step would leave its peers stuck in that step's gradient
+        # all-reduces, so the ranks agree on the batch size BEFORE any collective step -- from an estimate of the step's peak
+        # memory (measured on one GPU: 174.7 GB at 64 clips of 48 x 128 x 128, ch=32; activations dominate, linear in clips,
+        # frames, pixels and channels) against the free memory each rank reports, minimum over the ranks.
+        per_clip = 174.7 / 64 * (a.frames / 48) * (a.size / 128) ** 2 * (a.ch / 32) * 2 ** 30 * 1.05
+        free = torch.cuda.mem_get_info(dev)[0]
+        fit = [b for b in candidates if b * per_clip <= free] or [candidates[-1]]
+        pick = torch.tensor([float(fit[0])], device=dev)
+        dist.all_reduce(pick, op=dist.ReduceOp.MIN)
+        candidates = [int(pick)]
     tr = None
     for batch in candidates:
         cfg = argparse.Namespace(adv_loss="hinge", z_dim=120, g_chn=a.ch, ds_chn=a.ch, dt_chn=a.ch, n_frames=a.frames,
@@ -174,6 +185,7 @@ def main():
             labels = D.shard(torch.randint(0, a.n_class, (gB,), generator=gen), rank, world).to(dev)
             torch.manual_seed(100 + rank)                      # per-rank z / labels; frame ids come from the shared generator
             hidden = carried_states(a, batch, dev) if a.state_carry else None
+            tr.register_label_buffer(labels)                   # one device buffer for every step: range-checked once
             for _ in range(a.warmup):
                 tr.train_step(real, labels, hidden=hidden)
             ok = torch.ones(1, device=dev)
@@ -181,8 +193,6 @@ def main():
             if batch == candidates[-1]:
                 raise
             ok = torch.zeros(1, device=dev)
-        if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks move to the same batch size
         if float(ok) > 0:
             break
         tr = real = labels = hidden = None
@@ -191,25 +201,26 @@ def main():
     t0 = time.perf_counter()
     from dvd_gan_amd import functional as Fn
     for i in range(a.steps):
-        if i == a.steps - 1 and not a.no_kernel_prof:
-            # HIP events around every conv launch of the LAST timed step, recorded on the launch stream (5.4k event pairs cost
-            # ~2 % of a step, so not on all K).  In that step the weight-gradient kernels run on the launch stream as well
-            # instead of beside it: a kernel's duration is taken while it has the GPU to itself (the step is ~3 % slower for
-            # it, which `value` pays for once in K steps).
-            lib.dvd_prof_enable(1)
-            Fn.serialize_weight_grads(True)
         losses = tr.train_step(real, labels, hidden=hidden)
     sync()
-    dt = time.perf_counter() - t0
-    lib.dvd_prof_enable(0)
-    Fn.serialize_weight_grads(False)
+    dt = time.perf_counter() - t0               # exactly K steps in the execution mode training runs in
+    lossv = [float(v.detach()) for v in losses]
+    if not a.no_kernel_prof:
+        # One EXTRA step after the timed region (not part of `value`): HIP events around every conv launch, recorded on the
+        # launch stream, with the weight-gradient kernels on the launch stream as well instead of beside it -- a kernel's
+        # duration is taken while it has the GPU to itself.
+        lib.dvd_prof_enable(1)
+        Fn.serialize_weight_grads(True)
+        tr.train_step(real, labels, hidden=hidden)
+        sync()
+        lib.dvd_prof_enable(0)
+        Fn.serialize_weight_grads(False)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     ms = dt / a.steps * 1e3
     value = gB * a.steps / dt
-    lossv = [float(v.detach()) for v in losses]
 
     roof = None
     if not a.no_kernel_prof:
@@ -230,7 +241,7 @@ def main():
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),
                 "gflop_per_launch": round(dom["gflop_per_launch"], 2), "kernel_ms_per_step": round(dom["ms"], 1),
                 "wgrad": {k: round(v, 2) if isinstance(v, float) else v for k, v in res["conv_wgrad"].items()},
-                "timing": "HIP events on the launch stream around each launch of the last timed step, kernels serialised (no concurrent weight-gradient stream) in that step",
+                "timing": "HIP events on the launch stream around each launch of one extra step after the timed region, kernels serialised (no concurrent weight-gradient stream) in that step",
                 "step_achieved": round(value / world * F / 1e3, 1) if F else None,
                 "step_frac": round(value / world * F / 1e3 / peak, 4) if F else None}
     if rank == 0:

@@ -239,7 +239,10 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
     const long long nk = (long long)ntaps * ((C + bk - 1) / bk);
     const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     static const long long target_env = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 0;
-    const long long target = target_env ? target_env : (ntaps <= 9 ? 512 : 1024);
+    // round 3 (gate math batched in the conv epilogue, tools/gru_microbench.py sweep): a 5 x 5 conv with a short K loop
+    // (C = 128: 100 steps) no longer gains from a split plus gate kernel once it has 512 tiles (S = 32, h = 128:
+    // 180.5 / 208.7 -> 171.0 / 196.4 us per step forward / backward); the long loops (C = 512: 400 steps) still do
+    const long long target = target_env ? target_env : (ntaps <= 9 || nk < 200 ? 512 : 1024);
     long long ns = (target + tiles - 1) / tiles;
     static const long long cap = getenv("DVD_NS_CAP") ? atoll(getenv("DVD_NS_CAP")) : 16;
     if (ns > cap) ns = cap;

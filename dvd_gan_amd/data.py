@@ -162,14 +162,30 @@ def clips_to_device(clips, flips, device, norm_value=255.0, mean=(0.5, 0.5, 0.5)
     return out
 
 
-def make_loader(dataset, batch_size, num_workers=0, shuffle=True, device=None):
-    """DataLoader whose batches are (fp32 [B,3,T,S,S] on `device`, labels [B]) -- what Trainer.train expects."""
-    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, pin_memory=True,
-                             drop_last=True)
+def make_loader(dataset, batch_size, num_workers=0, shuffle=True, device=None, rank=None, world=None, seed=0):
+    """DataLoader whose batches are (fp32 [B,3,T,S,S] on `device`, labels [B]) -- what Trainer.train expects.
+    Two deliberate differences from the reference's DataLoader (main.py:57-62): the last, incomplete batch is DROPPED
+    (the generator's batch size is fixed by z, and the ConvGRU / CBN buffers are sized for it), so len(loader) -- and with it
+    steps_per_epoch / total_step / the log and save cadence of Trainer.train -- is floor(N / B), not ceil(N / B); and in a
+    data-parallel run (rank / world given, or read from torch.distributed) every rank iterates ITS OWN 1/world of a common
+    permutation (DistributedSampler seeded alike on all ranks; call `loader.set_epoch(e)` per epoch), so an epoch covers
+    the data once instead of world times."""
+    if world is None and torch.distributed.is_available() and torch.distributed.is_initialized():
+        world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+    sampler = None
+    if world is not None and world > 1:
+        sampler = data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed,
+                                                      drop_last=True)
+    loader = data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                             num_workers=num_workers, pin_memory=True, drop_last=True)
 
     class _OnDevice:
         def __len__(self):
             return len(loader)
+
+        def set_epoch(self, epoch):
+            if sampler is not None:
+                sampler.set_epoch(epoch)
 
         def __iter__(self):
             dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())

@@ -21,11 +21,15 @@ from . import lib as L
 #   * the big MFMA-bound weight-gradient launches fill the CUs the serial part of the backward pass leaves idle (the
 #     48-step BPTT of the 4x4 / 8x8 ConvGRUs runs 512-workgroup launches of 15-70 us back to back) and overlap the
 #     HBM-bound CBN / gate kernels.
-# `join_side()` (main stream waits for the side stream) must run before the gradients are read: Trainer does it after
-# every backward().  Parameters without a persistent .grad (stock optimizers with zero_grad(set_to_none=True), module
-# tests) take the autograd route unchanged.
+# The stream that ran backward() must wait for the side stream before the gradients are read.  That join is AUTOMATIC:
+# the first side-stream launch of a backward pass queues `join_side` as a final callback of the autograd engine, so it
+# runs when that backward() returns -- whoever called it (the Trainer, a drop-in loop with a stock optimizer and
+# zero_grad(set_to_none=False), gradient accumulation, a tool that drives tr.G directly).  The Trainer additionally joins
+# early where a gradient bucket is handed to the exchange.  Parameters without a persistent .grad (stock optimizers with
+# zero_grad(set_to_none=True), module tests) take the autograd route unchanged.
 import os as _os
-_SIDE = {"on": False, "stream": None, "serial": _os.environ.get("DVD_SIDE_SERIAL") == "1"}     # env: profiling aid, see below
+_SIDE = {"on": False, "stream": None, "serial": _os.environ.get("DVD_SIDE_SERIAL") == "1",      # env: profiling aid, see below
+         "cb": False}                                                                           # join callback queued for the running backward
 
 
 def direct_weight_grads(flag):
@@ -57,6 +61,22 @@ def join_side():
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
 
 
+def _join_after_backward():
+    _SIDE["cb"] = False
+    join_side()
+
+
+def _queue_join():
+    """Called from inside a backward pass: make the running backward() end with join_side()."""
+    if _SIDE["cb"]:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+        _SIDE["cb"] = True
+    except RuntimeError:          # not inside a backward pass (a Function.backward driven by hand): the caller joins
+        pass
+
+
 def _direct(*params):
     """True when every given parameter has a persistent fp32 .grad the kernels can accumulate into."""
     if not _SIDE["on"]:
@@ -82,6 +102,7 @@ class _on_side:
             self.cm = None
             return torch.cuda.current_stream()
         side = side_stream()
+        _queue_join()
         side.wait_stream(torch.cuda.current_stream())
         for t in self.tensors:
             t.record_stream(side)

@@ -62,6 +62,12 @@ class _PlateauLR:
     def step(self, metric):
         if metric is None:
             raise TypeError("step() missing 1 required positional argument: 'metrics'")
+        if D.world_size() > 1:
+            # data parallel: every rank must take the SAME lr decision or the replicas' parameters drift apart for good
+            # (only gradients are exchanged) -- the schedulers see the mean of the ranks' losses
+            metric = metric.detach().clone()
+            torch.distributed.all_reduce(metric, op=torch.distributed.ReduceOp.SUM)
+            metric = metric / D.world_size()
         m = float(metric)
         if m < self.best * (1.0 - self.threshold):
             self.best, self.bad = m, 0
@@ -114,6 +120,11 @@ class Trainer(object):
         # from a generator all ranks seed alike, z / labels from each rank's own default generator
         self._sync_replicas()
         self.frame_gen = torch.Generator().manual_seed(D.shared_seed()) if self.exchange.world > 1 else None
+        # ... and z / z_class of rank r from a generator seeded with (config.seed, r): distinct noise per replica whatever
+        # the caller did to the default generator (equal seeds on all ranks would train every replica on the same draws).
+        # A single process keeps the default generator -- the reference's behaviour (trainer.py:84-88, 236-240).
+        self.noise_gen = (torch.Generator().manual_seed(int(getattr(c, "seed", 0)) * 1000003 + 7919 * self.rank + 1)
+                          if self.exchange.world > 1 else None)
 
     # ---- trainer.py:345-366
     def build_model(self):
@@ -168,7 +179,7 @@ class Trainer(object):
 
     # ---- trainer.py:84-88
     def label_sample(self):
-        return torch.randint(low=0, high=self.n_class, size=(self.batch_size,)).to(self.device)
+        return torch.randint(low=0, high=self.n_class, size=(self.batch_size,), generator=self.noise_gen).to(self.device)
 
     # ---- trainer.py:384-387
     def reset_grad(self):
@@ -186,17 +197,21 @@ class Trainer(object):
         [0, n_class) while it is still on the host, like the IndexError nn.Embedding raises in the reference."""
         if not labels.numel():
             return labels
-        if labels.is_cuda:
-            # a device tensor costs a host sync to inspect: done once per distinct tensor (a loader that re-uses its
-            # label buffer, bench.py) -- labels normally arrive on the host (DataLoader, label_sample) and take the free path
-            key = (labels.data_ptr(), labels._version, labels.numel())
-            if getattr(self, "_labels_ok", None) == key:
-                return labels
-            self._labels_ok = key
+        if labels.is_cuda and getattr(self, "_labels_registered", None) is labels and self._labels_version == labels._version:
+            return labels           # a buffer the caller registered as persistent and has not written since (bench.py)
+        # (a device tensor costs a host sync to inspect -- labels normally arrive on the host (DataLoader, label_sample)
+        #  and take the free path; nothing is cached by address: a fresh tensor can reuse a freed block)
         lo, hi = int(labels.min()), int(labels.max())
         if lo < 0 or hi >= self.n_class:
             raise IndexError(f"class id out of range for n_class={self.n_class}: [{lo}, {hi}]")
         return labels
+
+    def register_label_buffer(self, labels):
+        """Declare a DEVICE label tensor the caller re-uses unchanged every step: it is validated now and not again while
+        its version counter stands (saves the host sync of the range check in a steady-state loop)."""
+        self._labels_registered = None
+        self._check_labels(labels)
+        self._labels_registered, self._labels_version = labels, labels._version
 
     def train_step(self, real_videos, real_labels, draws=None, hidden=None):
         """real_videos [B,3,T,H,W], real_labels [B].  `draws` (tests): dict with the reference's RNG
@@ -229,7 +244,8 @@ class Trainer(object):
                 draws = draws_all[_]
             ids_real = draw_frame_ids(T, k, fg) if draws is None else torch.as_tensor(draws["perm_real"])[:k].sort()[0]
             real_s = sample_k_frames(real_videos, T, k, ids_real)
-            z = (torch.randn(self.batch_size, self.z_dim) if draws is None else torch.as_tensor(draws["z"])).to(self.device)
+            z = (torch.randn(self.batch_size, self.z_dim, generator=self.noise_gen) if draws is None
+                 else torch.as_tensor(draws["z"])).to(self.device)
             z_class = self.label_sample() if draws is None else self._check_labels(torch.as_tensor(draws["z_class"])).to(self.device)
             ex.finish("G")
             fake_videos = self.G(z, z_class, hidden)

@@ -37,6 +37,11 @@ def golden():
     return get
 
 
+def from_bf16_bits(a):
+    """int16 array holding the upper halves of float32 words -> float32 array of the same shape."""
+    return (a.astype(np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
 def full_states(g):
     """Initial state_dicts (numpy) of G / D_s / D_t for a trainer fixture: stored entries verbatim, large tensors of a
     `meta.synth` fixture from the closed forms of tests/golden/synth.py (the generating script installed the same values
@@ -46,6 +51,9 @@ def full_states(g):
     from dvd_gan_amd.disc_nets import SpatialDiscriminator, TemporalDiscriminator
     from dvd_gan_amd.gen_net import Generator
     ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    if any(kk.startswith("G.sd0b.") for kk in g):            # bf16-representable state stored in 2 bytes per value (F14)
+        return [{**sub(g, tag + ".sd0"), **{kk: from_bf16_bits(v) for kk, v in sub(g, tag + ".sd0b").items()}}
+                for tag in ("G", "Ds", "Dt")]
     if not int(g.get("meta.synth", 0)):
         return [sub(g, tag + ".sd0") for tag in ("G", "Ds", "Dt")]
     import torch
@@ -62,6 +70,8 @@ def fixture_real(g, i):
     """Input clips [B,3,T,64,64] of batch i of a trainer fixture (stored, or the closed form for `meta.synth` fixtures)."""
     if f"in.real.{i}" in g:
         return g[f"in.real.{i}"]
+    if f"in.realb.{i}" in g:
+        return from_bf16_bits(g[f"in.realb.{i}"])
     sys.path.insert(0, GOLDEN)
     import synth
     ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]

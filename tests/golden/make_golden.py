@@ -363,13 +363,17 @@ def f8_helpers(R):
 
 # ----------------------------------------------------------------------------- F9 / F10
 def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr=5e-5,
-                grads_of=(), n_batches=None, synth_big=False, grad_head=None, d_iters=1):
+                grads_of=(), n_batches=None, synth_big=False, grad_head=None, d_iters=1, bf16_state=False):
     """Drive the unmodified reference Trainer.train() (trainer.py:189-307) on CPU and
     record every RNG draw, the six loss terms per step, named gradients and parameter
     checksums at each optimizer.step().
     synth_big: every floating-point state tensor with >= synth.BIG elements and the input clips are set to the
     closed-form values of tests/golden/synth.py BEFORE the reference runs, and are not stored.
     grad_head: store only the first `grad_head` elements (flattened) of each named gradient.
+    bf16_state: the reference's OWN default initialisation (orthogonal ConvGRU weights, ConvGRU.py:20-26, xavier attention
+    projections, N(0,1) SN vectors ...) and the input clips are rounded to bf16-representable values BEFORE the reference
+    runs, and stored as 2-byte values ('<tag>.sd0b.<key>', 'in.realb.<i>': the upper halves of the float32 words) -- a bf16
+    implementation then starts from exactly the reference's operands, and the fixture stays small.
     d_iters > 1 (trainer.py:230): the draws of discriminator iteration i of step s are stored as in.<name>.<s>.<i>; losses,
     gradients and checksums are those of the LAST discriminator iteration of the step (and of the generator update)."""
     import trainer as TR
@@ -394,16 +398,23 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
     else:
         loader = [((torch.rand(B, 3, T, 64, 64, generator=gen) * 2 - 1),
                    torch.randint(0, n_class, (B,), generator=gen)) for _ in range(nb_)]
+    if bf16_state:
+        loader = [(v.to(torch.bfloat16).float(), l) for v, l in loader]
     tr = TR.Trainer(loader, cfg)
     st = {}
     for net, tag in ((tr.G, "G"), (tr.D_s, "Ds"), (tr.D_t, "Dt")):
         for kk, v in net.state_dict().items():
-            if synth_big and v.is_floating_point() and v.numel() >= synth.BIG:
+            if bf16_state and v.is_floating_point():
+                v.copy_(v.to(torch.bfloat16).float())
+                st[f"{tag}.sd0b.{kk}"] = v.to(torch.bfloat16).view(torch.int16).numpy().copy()
+            elif synth_big and v.is_floating_point() and v.numel() >= synth.BIG:
                 v.copy_(torch.from_numpy(synth.weight(tag + "." + kk, tuple(v.shape))))    # state_dict tensors alias the parameters
             else:
                 st[f"{tag}.sd0.{kk}"] = npy(v)
     for i, (v, l) in enumerate(loader):
-        if not synth_big:
+        if bf16_state:
+            st[f"in.realb.{i}"] = v.to(torch.bfloat16).view(torch.int16).numpy().copy()
+        elif not synth_big:
             st[f"in.real.{i}"] = npy(v)
         st[f"in.labels.{i}"] = npy(l)
 
@@ -552,6 +563,25 @@ def f13_two_d_iters(R):
     save("f13_two_d_iters", st)
 
 
+F14_NAMES = ("conv.0.cells.1.update_gate.weight", "conv.3.cells.0.reset_gate.weight", "conv.9.cells.2.out_gate.weight",
+             "conv.1.conv0.module.weight_bar", "conv.10.CBNorm2.embed.weight", "embedding.weight", "colorize.module.weight_bar",
+             "pre_conv.0.module.weight_bar", "attn.value_conv.weight", "self_attn.query_conv.weight", "linear.module.weight_bar",
+             "res3d.conv1.module.weight_bar", "conv1.conv_sc.module.weight_bar", "conv2.2.conv1.module.weight_bar")
+
+
+def f14_default_init_bf16(R):
+    """ONE step of the unmodified reference Trainer from ITS OWN default initialisation -- the state a fresh model starts
+    from (orthogonal ConvGRU weights amplify perturbations over the recurrence far more than the uniform synth.py
+    weights of F10 / F11 do) -- at ch=4, T=16, 64x64, B=2, k=4, 3 classes, hinge, lr 5e-5, z_dim 120.  Every weight,
+    buffer and input clip is rounded to bf16 before the reference runs and stored in 2 bytes (run_trainer, bf16_state):
+    the bf16 mode of the HIP path is compared on identical operands.  Stored: the six losses, |grad| checksums of every
+    parameter, the first 4096 elements of the named gradients, the post-step SN / BN state."""
+    st = run_trainer(R, adv_loss="hinge", ch=4, T=16, k=4, B=2, n_class=3, steps=1, seed=170, z_dim=120, lr=5e-5,
+                     grads_of=F14_NAMES, grad_head=4096, bf16_state=True)
+    keep = {k: v for k, v in st.items() if not (".sd1." in k and v.size >= 4096)}
+    save("f14_default_init_bf16", keep)
+
+
 def f12_ucf101_reader(R):
     """Real-data input path: a tiny synthetic UCF-101-style JPEG folder (2 classes, 3 videos of 9-14 frames, 40x30 pixels)
     read through the reference's UCF101 dataset (Dataloader/datasets/ucf101.py) with the training transforms main.py:42-55
@@ -615,7 +645,7 @@ def f12_ucf101_reader(R):
 ALL = {"f1": f1_spectral_norm, "f2": f2_conditional_norm, "f3": f3_gresblock, "f4": f4_convgru,
        "f5": f5_attention, "f6": f6_generator, "f7": f7_discriminators, "f8": f8_helpers,
        "f9": f9_trainer_steps, "f10": f10_config1, "f11": f11_full_width,
-       "f12": f12_ucf101_reader, "f13": f13_two_d_iters}
+       "f12": f12_ucf101_reader, "f13": f13_two_d_iters, "f14": f14_default_init_bf16}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -72,3 +72,44 @@ def test_reference_loop_with_stock_adam(golden):
         ref = g[f"out.psum.{s}.G"]
         big = ref > 1.0
         np.testing.assert_allclose(psum[big], ref[big], rtol=1e-3 if s == 0 else 2e-2)
+
+
+def test_persistent_grads_are_joined_when_backward_returns(golden):
+    """once a Trainer has switched the direct weight-gradient route on, ANY backward() over parameters whose .grad
+    is a persistent fp32 buffer (stock optimizer + zero_grad(set_to_none=False), gradient accumulation, a tool driving
+    the generator alone) accumulates on the side stream.  The join is queued as a final callback of the autograd engine:
+    when backward() returns the calling stream already waits for it, so reading / stepping right away is race-free.
+    Checked against the autograd route on the same generator: identical gradients, twice in a row (accumulation)."""
+    from dvd_gan_amd import functional as Fn
+    from dvd_gan_amd.gen_net import Generator
+    g = golden("f9_trainer_hinge")
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    G = Generator(z_dim, 4, n_class, ch, T, compute_dtype=torch.float32)
+    G.load_state_dict({kk: torch.as_tensor(v) for kk, v in sub(g, "G.sd0").items()})
+    G = G.cuda().train()
+    sd0 = {kk: v.clone() for kk, v in G.state_dict().items()}
+    z, zc = torch.as_tensor(g["in.z.0"]).cuda(), torch.as_tensor(g["in.z_class.0"]).cuda()
+    w = torch.randn(B, T, 3, 64, 64, device="cuda")
+
+    def two_backwards(direct):
+        G.load_state_dict(sd0)                                  # same SN u / v, BN statistics for both routes
+        Fn.direct_weight_grads(direct)
+        for p in G.parameters():
+            p.grad = torch.zeros_like(p) if (direct and p.requires_grad) else None    # persistent buffers <-> set-to-none
+        for _ in range(2):                                      # second pass accumulates
+            (G(z, zc) * w).sum().backward()
+        # no join_side() here on purpose: the gradients are read straight after backward()
+        return {kk: p.grad.detach().clone() for kk, p in G.named_parameters() if p.grad is not None}
+    try:
+        ref = two_backwards(False)
+        got = two_backwards(True)
+        assert Fn._SIDE["stream"] is not None                   # the side stream really was used
+    finally:
+        Fn.direct_weight_grads(False)
+    assert set(got) == set(ref)
+    scale = max(float(v.norm()) for v in ref.values())
+    for kk in ref:
+        # (a bias in front of a batch norm has a mathematically zero gradient: rounding noise in both routes, hence the
+        #  absolute term)
+        d = float((got[kk] - ref[kk]).norm())
+        assert d < 1e-5 * float(ref[kk].norm()) + 1e-6 * scale, (kk, d, float(ref[kk].norm()))

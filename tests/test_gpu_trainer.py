@@ -263,3 +263,131 @@ def test_temporal_discriminator_rejects_frame_counts_it_cannot_pool():
     D = TemporalDiscriminator(2, 3, compute_dtype=torch.float32).to(DEV)
     with pytest.raises(ValueError, match="multiple of 4"):
         D(torch.zeros(1, 3, 6, 32, 32, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
+
+
+# ------------------------------------------------------------------ bf16 at the reference's own initialisation (F14)
+def _snap_step(tr, g, s=0):
+    """One train_step on the fixture's draws with the gradients captured right before each Adam launch."""
+    snap = {}
+    for tag, net, opt in (("Ds", tr.D_s, tr.ds_optimizer), ("Dt", tr.D_t, tr.dt_optimizer), ("G", tr.G, tr.g_optimizer)):
+        def wrap(opt=opt, net=net, tag=tag, orig=opt.step):
+            def stepper():
+                if tag not in snap:
+                    snap[tag] = {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+                orig()
+            return stepper
+        opt.step = wrap()
+    draws = {"perm_real": g[f"in.perm_real.{s}"], "z": g[f"in.z.{s}"], "z_class": g[f"in.z_class.{s}"],
+             "perm_fake": g[f"in.perm_fake.{s}"]}
+    losses = tr.train_step(torch.as_tensor(fixture_real(g, s)), torch.as_tensor(g[f"in.labels.{s}"]), draws)
+    return [float(v.detach()) for v in losses], snap
+
+
+def _cos(a, b):
+    """cosine of two gradients; 1.0 when the reference gradient is exactly zero and so is ours (attention projections
+    behind gamma = 0, Discriminators.py:91), 0.0 when only one of them is"""
+    a, b = a.double().reshape(-1), torch.as_tensor(b).double().reshape(-1)
+    if float(b.norm()) == 0.0:
+        return 1.0 if float(a.norm()) == 0.0 else 0.0
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+F14_NUMBERS = {}
+
+
+@pytest.mark.parametrize("mode", ["exact", "bf16", "ulp"])
+def test_step_at_reference_default_init(golden, mode):
+    """ONE step from the reference's own default initialisation (orthogonal ConvGRU weights: the state a fresh model starts
+    from), all weights / clips bf16-representable so the bf16 mode sees exactly the reference's operands (fixture F14,
+    ch=4, T=16, B=2).  Three runs against the reference's recorded step:
+      exact : fp32 path.  Six losses 2e-3 rel / 2e-4 abs (measured 2e-7); |grad| checksum of every parameter 1e-2 rel
+              (measured 9e-4); named gradients cosine >= 0.9999.
+      bf16  : the timed mode.  Six losses within 1e-2 absolute -- SURVEY section 8c's bound (measured 1.5e-3); D_s / D_t:
+              checksum vector rel-L2 <= 1e-2 (measured 1.7e-3), named gradients cosine >= 0.999 (measured 0.9998); G:
+              named gradients cosine >= 0.9 (measured 0.937 ... 0.9999: the early layers sit behind all four recurrences).
+      ulp   : exact mode with every weight moved by ONE bf16 ulp (relative 2^-9, random sign) -- the least any bf16
+              implementation perturbs them.  It yields the sensitivity the bf16 numbers are judged against: asserted below
+              that the bf16 mode's loss errors and generator-gradient misalignment (1 - cosine) stay within 3x the
+              one-ulp run's (+ 1e-3), i.e. the 0.94 is the conditioning of the recurrence at this initialisation, not
+              kernel error."""
+    import json, os
+    g = golden("f14_default_init_bf16")
+    exact = mode != "bf16"
+    tr, _ = make_trainer(g, g, "hinge", torch.float32 if exact else torch.bfloat16)
+    if mode == "ulp":
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        with torch.no_grad():
+            for net in (tr.G, tr.D_s, tr.D_t):
+                for p in net.parameters():
+                    if p.requires_grad:
+                        sgn = torch.randint(0, 2, p.shape, generator=gen, device=p.device).float() * 2 - 1
+                        p.mul_(1 + sgn * 2.0 ** -9)
+    losses, snap = _snap_step(tr, g)
+    want = g["out.losses.0"]
+    rec = {"loss_abs_err": [abs(a - b) for a, b in zip(losses, want)], "losses": losses, "want": [float(v) for v in want]}
+    for tag in ("Ds", "Dt", "G"):
+        keys = [str(x) for x in g[f"meta.gsum_keys.{tag}"]]
+        got = np.array([float(snap[tag][kk].double().abs().sum()) for kk in keys])
+        ref = g[f"out.gsum.0.{tag}"]
+        rec[f"gsum_relL2_{tag}"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        big = ref > 1e-3 * ref.max()
+        rec[f"gsum_maxrel_{tag}"] = float(np.max(np.abs(got[big] - ref[big]) / ref[big]))
+        cs = {kk: _cos(snap[tag][kk].reshape(-1)[:v.size], v) for kk, v in sub(g, f"grad.0.{tag}").items()}
+        rec[f"cos_min_{tag}"] = min(cs.values())
+        rec[f"cos_{tag}"] = cs
+    F14_NUMBERS[mode] = rec
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/f14_numbers.json", "w") as f:
+        json.dump(F14_NUMBERS, f, indent=1)
+    if mode == "exact":
+        np.testing.assert_allclose(losses, want, rtol=2e-3, atol=2e-4)
+        for tag in ("Ds", "Dt", "G"):
+            assert rec[f"gsum_maxrel_{tag}"] < 1e-2, (tag, rec[f"gsum_maxrel_{tag}"])
+            assert rec[f"cos_min_{tag}"] > 0.9999, (tag, rec[f"cos_{tag}"])
+    elif mode == "bf16":
+        np.testing.assert_allclose(losses, want, atol=1e-2, rtol=0)
+        for tag in ("Ds", "Dt"):
+            assert rec[f"gsum_relL2_{tag}"] < 1e-2, (tag, rec[f"gsum_relL2_{tag}"])
+            assert rec[f"cos_min_{tag}"] > 0.999, (tag, rec[f"cos_{tag}"])
+        assert rec["cos_min_G"] > 0.9, rec["cos_G"]
+    else:
+        assert "bf16" in F14_NUMBERS, "runs after the bf16 case"
+        b = F14_NUMBERS["bf16"]
+        assert max(b["loss_abs_err"]) <= 3 * max(rec["loss_abs_err"]) + 1e-3, (b["loss_abs_err"], rec["loss_abs_err"])
+        for kk, c in b["cos_G"].items():
+            assert 1 - c <= 3 * (1 - rec["cos_G"][kk]) + 1e-3, (kk, c, rec["cos_G"][kk])
+
+
+def test_bf16_trajectory_follows_exact_mode(golden):
+    """20 optimizer steps from the reference's default initialisation (F14 state, ch=4, T=16, B=2, hinge, lr 5e-5) in exact
+    mode and in bf16 mode on the same clips and RNG draws: the bf16 trajectory must stay beside the exact one -- every
+    loss term within 1e-2 absolute at every step (measured: 4.1e-3 at worst, no growth over the 20 steps), nothing
+    non-finite, and the parameter displacement of the two runs (both have moved every weight by ~20 Adam steps of 5e-5)
+    agreeing to cosine >= 0.99 for each network (measured 0.9995 / 0.99999 / 0.99999)."""
+    import json, os
+    g = golden("f14_default_init_bf16")
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    runs = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        tr, _ = make_trainer(g, g, "hinge", dtype)
+        p0 = [torch.cat([p.detach().reshape(-1).cpu() for p in net.parameters()]) for net in (tr.G, tr.D_s, tr.D_t)]
+        gen = torch.Generator().manual_seed(77)
+        hist = []
+        for s in range(20):
+            real = (torch.rand(B, 3, T, 64, 64, generator=gen) * 2 - 1).to(torch.bfloat16).float()
+            labels = torch.randint(0, n_class, (B,), generator=gen)
+            draws = {"perm_real": torch.randperm(T, generator=gen), "z": torch.randn(B, z_dim, generator=gen),
+                     "z_class": torch.randint(0, n_class, (B,), generator=gen), "perm_fake": torch.randperm(T, generator=gen)}
+            hist.append([float(v.detach()) for v in tr.train_step(real, labels, draws)])
+        p1 = [torch.cat([p.detach().reshape(-1).cpu() for p in net.parameters()]) for net in (tr.G, tr.D_s, tr.D_t)]
+        runs[dtype] = (np.array(hist), [b - a for a, b in zip(p0, p1)])
+    he, hb = runs[torch.float32][0], runs[torch.bfloat16][0]
+    assert np.isfinite(he).all() and np.isfinite(hb).all()
+    dev = np.abs(he - hb)
+    cos = [_cos(a, b) for a, b in zip(runs[torch.float32][1], runs[torch.bfloat16][1])]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/f14_trajectory.json", "w") as f:
+        json.dump({"max_abs_dev_per_term": dev.max(0).tolist(), "max_abs_dev_per_step": dev.max(1).tolist(),
+                   "displacement_cosine_G_Ds_Dt": cos, "exact_losses": he.tolist(), "bf16_losses": hb.tolist()}, f, indent=1)
+    assert dev.max() < 1e-2, dev.max(0)
+    assert min(cos) > 0.99, cos

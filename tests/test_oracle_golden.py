@@ -300,3 +300,31 @@ def test_f11_full_width_step(golden):
         np.testing.assert_allclose(got, g[f"out.gsum.0.{tag}"], rtol=2e-3, err_msg=f"{tag} gradient checksums")
         for kk, v in sub(g, f"grad.0.{tag}").items():
             close(snaps[tag][kk].reshape(-1)[:v.size], v, 2e-3, 1e-7, what=f"{tag} grad {kk}")
+
+
+# ------------------------------------------------------------------ F14: the reference's own default initialisation
+def test_f14_default_init_step(golden):
+    """The oracle against ONE step of the real reference started from ITS OWN default initialisation (orthogonal ConvGRU
+    weights, ConvGRU.py:20-26) at ch=4, T=16, B=2 -- every weight and clip bf16-representable, stored in 2 bytes: losses,
+    |grad| checksums of every parameter, heads of the named gradients, post-step SN / BN state."""
+    g = golden("f14_default_init_bf16")
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    sds = full_states(g)
+    for sd in sds:                                   # the decoder restores exactly bf16-representable float32 values
+        for kk, v in sd.items():
+            if v.dtype == np.float32:
+                assert np.array_equal(t(v).to(torch.bfloat16).float().numpy(), v), kk
+    st = O.TrainState(O.make_state(sds[0]), O.make_state(sds[1]), O.make_state(sds[2]), ch=ch, n_frames=T, k_sample=k,
+                      n_class=n_class, z_dim=z_dim, adv="hinge", g_lr=float(g["meta.lr"]), d_lr=float(g["meta.lr"]))
+    snaps = O.snapshot_grads(st)
+    losses = O.train_step(st, t(fixture_real(g, 0)), t(g["in.labels.0"]), t(g["in.z.0"]), t(g["in.z_class.0"]),
+                          g["in.perm_real.0"], g["in.perm_fake.0"])
+    np.testing.assert_allclose(losses, g["out.losses.0"], rtol=2e-4, atol=2e-5)
+    for tag in ("Ds", "Dt", "G"):
+        keys = [str(x) for x in g[f"meta.gsum_keys.{tag}"]]
+        got = np.array([float(snaps[tag][kk].double().abs().sum()) for kk in keys])
+        np.testing.assert_allclose(got, g[f"out.gsum.0.{tag}"], rtol=2e-3, atol=1e-9, err_msg=f"{tag} gradient checksums")
+        for kk, v in sub(g, f"grad.0.{tag}").items():
+            close(snaps[tag][kk].reshape(-1)[:v.size], v, 2e-3, 1e-7, what=f"{tag} grad {kk}")
+    for tag, sd in (("G", st.G), ("Ds", st.Ds), ("Dt", st.Dt)):
+        check_state(sd, sub(g, tag + ".sd1"), 1e-3)

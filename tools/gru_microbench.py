@@ -112,7 +112,37 @@ def halves(iters, B, T):
             print(f"{LAYERS[i][0]} {fn_name[19:]:9s}: whole batch {t1:7.2f} ms   two halves on two streams {t2:7.2f} ms   ({100 * (1 - t2 / t1):5.1f} % saved)", flush=True)
 
 
+def parts(iters, B, T, n, sel):
+    """One layer at batch B on one stream vs n equal parts of the batch (independent recurrences) on n streams."""
+    dev, dt = "cuda", torch.bfloat16
+    lib = L.lib()
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    for i in sel:
+        full, kf = setup(*LAYERS[i], B, T, dev, dt, lib)
+        ps = [setup(*LAYERS[i], B // n, T, dev, dt, lib) for _ in range(n)]
+        for fn_name in ("dvd_convgru_layer_forward", "dvd_convgru_layer_backward"):
+            fn = getattr(lib, fn_name)
+
+            def one():
+                L.check(fn(C.byref(full), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+            def many():
+                cur = torch.cuda.current_stream()
+                for st_ in streams:
+                    st_.wait_stream(cur)
+                for (d_, _), st_ in zip(ps, streams):
+                    L.check(fn(C.byref(d_), C.c_void_p(st_.cuda_stream)))
+                for st_ in streams:
+                    cur.wait_stream(st_)
+            t1, t2 = timed(one, iters), timed(many, iters)
+            print(f"{LAYERS[i][0]} {fn_name[19:]:9s}: whole batch {t1:7.2f} ms   {n} parts on {n} streams {t2:7.2f} ms   ({100 * (1 - t2 / t1):5.1f} % saved)", flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "parts":
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+        sel = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(LAYERS))
+        return parts(3, 64, 48, n, sel)
     if len(sys.argv) > 1 and sys.argv[1] == "pairs":
         return pairs(3, 64, 48)
     if len(sys.argv) > 1 and sys.argv[1] == "halves":
