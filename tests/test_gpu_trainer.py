@@ -4,7 +4,9 @@ Trainer (golden F9: two steps, hinge and wgan-gp; F10: config-1 plumbing, three 
 Exact mode (f32 MFMA): the six loss terms per step within 2e-3 relative / 2e-4 absolute of the
 reference (two optimizer steps deep; the fixtures amplify fp32 rounding ~100x, see
 test_gpu_modules.GEN_TOL), post-step parameter checksums within 3e-2 (see comment), named gradients rel-L2 < 2e-2.
-bf16 mode: losses within 0.15 absolute (smoke-level: the ch=2 fixtures are ill-conditioned).
+bf16 mode: F9 losses within 2e-2 (step 0) / 5e-2 (step 1, after an Adam step at 40x the reference lr) absolute; F14 (one
+step from the reference's OWN default initialisation, bf16-representable state): losses within 1e-2,
+gradients judged against the one-ulp sensitivity of the exact mode; 20-step bf16-vs-exact trajectory within 1e-2.
 """
 import argparse
 
@@ -87,7 +89,10 @@ def run(g, base, adv, dtype):
             big = ref > 1.0                  # zero-initialised biases are sums of +-lr noise steps
             np.testing.assert_allclose(got[big], ref[big], rtol=1e-3 if s == 0 else 2e-2, err_msg=f"G checksums step {s}")
         else:
-            np.testing.assert_allclose(out[-1], want, atol=0.15, err_msg=f"losses step {s}")
+            # bf16 on F9 (ch=2, weights NOT bf16-representable, lr 2e-3 = 40x the reference's): measured 8.1e-3 at step 0 and
+            # 1.9e-2 one (large) Adam step later.  The tight statement of the timed mode -- 1e-2 at the reference's own
+            # initialisation, judged against the one-ulp sensitivity -- is test_step_at_reference_default_init (F14).
+            np.testing.assert_allclose(out[-1], want, atol=2e-2 if s == 0 else 5e-2, err_msg=f"losses step {s}")
     return tr, out
 
 
