@@ -631,45 +631,52 @@ template <bool UP2> struct HaloGeo {
 
 // waves: WMV (M) x WN (N); block tile (WMV*TM*32 pixels) x (WN*64).  WMV = 4, TM = 2, WN = 1 is the 256 x 64 tile of
 // the thin convs (Cout <= 64: a 128-wide N tile would multiply zeros half of the time)
-template <typename T, int TM, int WN, bool RELU, bool UP2, int WMV = 2>
-__global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
-    using G = HaloGeo<UP2>;
-    constexpr int PITCH = G::PITCH;
-    constexpr int E16 = ElemTraits<T>::kPer16B;
-    constexpr int BK = 4 * E16;
-    constexpr int BMt = WMV * TM * 32, BNt = WN * 64;
-    constexpr int NWAVE = WMV * WN;
-    constexpr int PH = BMt / 16;                              // patch: PH rows x 16 columns of one frame
-    constexpr int HG = UP2 ? ((PH / 2 + 3) * PITCH + 15) / 16 // 16-row DMA groups of the largest footprint
-                           : ((PH + 4) * PITCH + 15) / 16;    //   (5 x 5 taps)
-    constexpr int NH = (HG + NWAVE - 1) / NWAVE;              // footprint DMAs per wave
-    constexpr int NB = BNt / 16 / NWAVE;                      // weight-tile DMAs per wave
-    constexpr int HBYTES = HG * 1024, BBYTES = BNt * 64;
+// compile-time geometry of one halo-kernel variant
+template <typename T, int TM, int WN, bool UP2, int WMV> struct HaloCfg {
+    static constexpr int PITCH = HaloGeo<UP2>::PITCH;
+    static constexpr int BMt = WMV * TM * 32, BNt = WN * 64;
+    static constexpr int NWAVE = WMV * WN;
+    static constexpr int PH = BMt / 16;                              // patch: PH rows x 16 columns of one frame
+    static constexpr int HG = UP2 ? ((PH / 2 + 3) * PITCH + 15) / 16 // 16-row DMA groups of the largest footprint
+                                  : ((PH + 4) * PITCH + 15) / 16;    //   (5 x 5 taps)
+    static constexpr int HBYTES = HG * 1024, BBYTES = BNt * 64;
     // weight ring depth: NSTAGE-1 tiles in flight.  4 where LDS allows (the 256 x 128 variant runs 2 workgroups per CU)
     // (a fourth stage for the 3 x 3 filters, whose smaller footprint leaves room for it at two workgroups per CU, measured
     //  +0.6 %: the ring depth is not what limits the loop)
-    constexpr int NSTAGE = (TM == 4 && WN == 2) ? 3 : 4;
-    constexpr int EPI = NWAVE * 32 * 64 * 4;
-    constexpr int LDSB = 2 * HBYTES + 1024 + NSTAGE * BBYTES > EPI ? 2 * HBYTES + 1024 + NSTAGE * BBYTES : EPI;
-    __shared__ __attribute__((aligned(16))) char smem[LDSB];
+    static constexpr int NSTAGE = (TM == 4 && WN == 2) ? 3 : 4;
+    static constexpr int EPI = NWAVE * 32 * 64 * 4;
+    static constexpr int LDSB = 2 * HBYTES + 1024 + NSTAGE * BBYTES > EPI ? 2 * HBYTES + 1024 + NSTAGE * BBYTES : EPI;
+};
+
+// One output tile (M tile mt = a patch of one frame, N tile nt, K slice z) of the halo-staged convolution; `smem`: the
+// workgroup's LDS block of HaloCfg::LDSB bytes (the ONLY __shared__ object of the calling kernel: a second one makes hipcc
+// drain vmcnt before the LDS reads of every K step).  Called once per workgroup by conv_halo_kernel and once per tile by
+// the persistent ConvGRU kernels (gru_persist_*), which place a workgroup barrier between two tiles.
+template <typename T, int TM, int WN, bool RELU, bool UP2, int WMV = 2>
+__device__ __forceinline__ void conv_halo_tile(const ConvK& p, char* const smem, const int mt, const int nt, const int z) {
+    using G = HaloGeo<UP2>;
+    using Cfg = HaloCfg<T, TM, WN, UP2, WMV>;
+    constexpr int PITCH = G::PITCH;
+    constexpr int E16 = ElemTraits<T>::kPer16B;
+    constexpr int BK = 4 * E16;
+    constexpr int BMt = Cfg::BMt, BNt = Cfg::BNt;
+    constexpr int NWAVE = Cfg::NWAVE;
+    constexpr int PH = Cfg::PH;
+    constexpr int HG = Cfg::HG;
+    constexpr int NH = (HG + NWAVE - 1) / NWAVE;              // footprint DMAs per wave
+    constexpr int NB = BNt / 16 / NWAVE;                      // weight-tile DMAs per wave
+    constexpr int HBYTES = Cfg::HBYTES, BBYTES = Cfg::BBYTES;
+    constexpr int NSTAGE = Cfg::NSTAGE;
     char* const hbuf0 = &smem[0];
     char* const dump = &smem[2 * HBYTES];                     // landing zone of the DMAs of non-existent groups
     char* const bring = &smem[2 * HBYTES + 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rr = nwg & 7;
-        bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
-    }
-    int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
-    if (p.nmajor) { const int tilesM = gridDim.x / p.tilesN; nt = bid / tilesM; mt = bid - nt * tilesM; }
     const int n0 = nt * BNt;
     // tile -> (frame, patch origin)
     const int pw = p.W >> 4, ppf = pw * (p.H / PH);
     const int ft = mt / ppf, pidx = mt - ft * ppf;
     const int y0 = (pidx / pw) * PH, x0 = (pidx % pw) * 16;
-    const int z = blockIdx.z;
     const int nouter = p.kchunks * p.kt;                      // outer index oc = cc * kt + it
     const int per = (nouter + p.nsplit - 1) / p.nsplit;
     const int oc_begin = z * per, oc_end = min(nouter, oc_begin + per);
@@ -877,6 +884,19 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
         const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;          // pixel of the patch, row-major 16 wide
         return (y0 + (pi >> 4)) * p.W + x0 + (pi & 15);
     });
+}
+
+template <typename T, int TM, int WN, bool RELU, bool UP2, int WMV = 2>
+__global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
+    __shared__ __attribute__((aligned(16))) char smem[HaloCfg<T, TM, WN, UP2, WMV>::LDSB];
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
+    }
+    int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    if (p.nmajor) { const int tilesM = gridDim.x / p.tilesN; nt = bid / tilesM; mt = bid - nt * tilesM; }
+    conv_halo_tile<T, TM, WN, RELU, UP2, WMV>(p, smem, mt, nt, blockIdx.z);
 }
 
 // ============================================================================ backward-weight

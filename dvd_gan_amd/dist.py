@@ -67,7 +67,14 @@ class GradExchange:
 
     def __init__(self):
         self.world = world_size()
-        self.stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        self.stream = None
+        if self.world > 1 and torch.cuda.is_available():
+            # The exchange runs on the most urgent priority level: RCCL's all-reduce kernels need a few CUs' worth of
+            # workgroup slots, and the step's own launches (two workgroups on every CU, back to back) would otherwise be
+            # dispatched ahead of them at every kernel boundary.  DVD_EXCHANGE_PRIO=0 puts it on a default-priority stream.
+            # (No multi-GPU hardware was available to this build: the setting is by construction, not by measurement.)
+            hi = torch.cuda.Stream.priority_range()[1] if os.environ.get("DVD_EXCHANGE_PRIO", "1") != "0" else 0
+            self.stream = torch.cuda.Stream(priority=hi)
         self.pending = {}
 
     def _launch(self, key, view):

@@ -108,10 +108,15 @@ class Trainer(object):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.compute_dtype, self.latent_dim = compute_dtype, latent_dim
         Fn.direct_weight_grads(True)          # weight gradients accumulate into FlatAdam's buffers on a side stream
-        self._chain = None
-        if torch.cuda.is_available() and os.environ.get("DVD_CHAIN_PRIO", "1") != "0":
-            self._chain = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
         self.exchange = GradExchange()
+        # The step's dependent chain runs on a high-priority stream (ahead of the bulk weight-gradient stream) -- in a
+        # single-process run.  In a data-parallel run the gradient exchange takes the urgent level instead and the chain
+        # stays on the caller's stream, so RCCL's kernels are not queued behind every launch of the step while an exchange
+        # is pending.  DVD_CHAIN_PRIO=1 / 0 forces the high-priority chain on / off.
+        prio = os.environ.get("DVD_CHAIN_PRIO", "auto")
+        self._chain = None
+        if torch.cuda.is_available() and (prio == "1" or (prio == "auto" and self.exchange.world == 1)):
+            self._chain = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
         self.rank = torch.distributed.get_rank() if self.exchange.world > 1 else 0
         self.build_model()
         if self.pretrained_model:

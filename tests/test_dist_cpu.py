@@ -92,3 +92,43 @@ def test_two_rank_gradient_exchange_equals_global_batch():
     _, full = _ds_grads(g, torch.as_tensor(g["ds.in.x"]), torch.as_tensor(g["ds.in.cls"]))
     np.testing.assert_allclose(out[0], out[1], rtol=0, atol=0)
     np.testing.assert_allclose(out[0], full.numpy(), rtol=2e-4, atol=2e-6)
+
+
+def _worker4(rank, world, port, out):
+    """World size 4: the generator's bucketed exchange in the Trainer's order (tail of the flat buffer first, uneven bucket
+    sizes incl. an empty one), the row gather and the shared seed."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from dvd_gan_amd import dist as D
+    r, w, dev = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    n = 10007
+    gen = torch.Generator().manual_seed(5)
+    parts = torch.randn(world, n, generator=gen)                  # every rank knows every rank's gradient
+    flat = parts[rank].clone()
+    ex = D.GradExchange()
+    hi = n
+    for lo in (9000, 9000, 4097, 1, 0):                           # the on_ready hook's [lo, hi) ranges, an empty one included
+        ex.start_range("G", flat, lo, hi)
+        hi = min(hi, lo)
+    ex.finish("G")
+    assert torch.allclose(flat, parts.mean(0), rtol=0, atol=1e-6)
+    rows = (torch.arange(3.).view(1, 3) + 10 * rank).requires_grad_(True)
+    allr = D.AllGatherRows.apply(rows)
+    assert torch.equal(allr.detach(), torch.cat([torch.arange(3.).view(1, 3) + 10 * q for q in range(world)]))
+    (allr * (rank + 1)).sum().backward()
+    assert torch.equal(rows.grad, torch.full((1, 3), float(sum(range(1, world + 1)))))
+    seeds = [None] * world
+    torch.distributed.all_gather_object(seeds, D.shared_seed())
+    assert len(set(seeds)) == 1
+    out[rank] = 1
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_four_rank_bucketed_exchange():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker4, args=(4, _free_port(), out), nprocs=4, join=True)
+    assert sorted(out.keys()) == [0, 1, 2, 3]

@@ -102,17 +102,20 @@ def _check_replica_mode(two, one):
 
 def _check_global_mode(two, one):
     """N ranks == 1 rank: losses (mean of the per-rank means), every gradient after the exchange, BN running statistics."""
-    for k, v in two[0]["G"].items():
-        assert torch.equal(v, two[1]["G"][k]), k                          # now the BN buffers agree as well
+    n = len(two)
+    for r in range(1, n):
+        for k, v in two[0]["G"].items():
+            assert torch.equal(v, two[r]["G"][k]), k                      # now the BN buffers agree as well
     for i in range(6):
-        assert abs(0.5 * (two[0]["losses"][i] + two[1]["losses"][i]) - one["losses"][i]) < 2e-5, i
+        assert abs(sum(t["losses"][i] for t in two) / n - one["losses"][i]) < 2e-5, i
     worst = 0.0
     for net in ("Ds", "Dt", "G"):
         ref = one["grads"][net]
         scale = max(float(v.abs().max()) for v in ref.values())
         for k, v in ref.items():
             got = two[0]["grads"][net][k]
-            assert torch.equal(got, two[1]["grads"][net][k]), (net, k)
+            for r in range(1, n):
+                assert torch.equal(got, two[r]["grads"][net][k]), (net, k)
             if float(v.abs().max()) < 1e-4 * scale:
                 continue
             r = float((got.double() - v.double()).norm() / v.double().norm())
@@ -130,6 +133,13 @@ def test_two_ranks_one_gpu_match_each_other_and_the_global_batch(tmp_path):
 
 def test_two_ranks_global_mode_equal_one_process_on_the_global_batch(tmp_path):
     _check_global_mode(_run(2, str(tmp_path), mode="global"), _single(str(tmp_path)))
+
+
+def test_four_ranks_global_mode_equal_one_process_on_the_global_batch(tmp_path):
+    """World size 4 (one clip per rank, four ranks on one GPU over gloo): the generator's gradient goes in its four buckets
+    (stage-boundary hooks), cross-replica batch norm sums over four replicas, the condition rows of four ranks are
+    gathered -- and the result is still ONE process on the global batch of four clips."""
+    _check_global_mode(_run(4, str(tmp_path), mode="global"), _single(str(tmp_path)))
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL path needs two GPUs (one rank per GPU)")
