@@ -650,8 +650,9 @@ template <typename T, int TM, int WN, bool UP2, int WMV> struct HaloCfg {
 
 // One output tile (M tile mt = a patch of one frame, N tile nt, K slice z) of the halo-staged convolution; `smem`: the
 // workgroup's LDS block of HaloCfg::LDSB bytes (the ONLY __shared__ object of the calling kernel: a second one makes hipcc
-// drain vmcnt before the LDS reads of every K step).  Called once per workgroup by conv_halo_kernel and once per tile by
-// the persistent ConvGRU kernels (gru_persist_*), which place a workgroup barrier between two tiles.
+// drain vmcnt before the LDS reads of every K step).  conv_halo_kernel calls it once per workgroup; a caller that runs
+// several tiles in one workgroup (the persistent time-loop experiment of round 3) places a workgroup
+// barrier between two tiles.
 template <typename T, int TM, int WN, bool RELU, bool UP2, int WMV = 2>
 __device__ __forceinline__ void conv_halo_tile(const ConvK& p, char* const smem, const int mt, const int nt, const int z) {
     using G = HaloGeo<UP2>;
@@ -1630,7 +1631,9 @@ extern "C" long long dvd_prof_report(int kind, double* total_ms, double* total_f
 // ============================================================================ C ABI
 extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) { return dvd_conv_forward_gru(d, nullptr, stream); }
 
-extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream) {
+// Validates a forward / backward-data request and derives the kernel parameters and the variant that serves it.
+struct ConvPlan { long long M; bool halo, thin, wide, big; };
+static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan& pl) {
     if (!d || !d->in || !d->w || (!d->ws && (!d->out || d->nsplit > 1))) return DVD_E_ARG;
     if (g && (d->ws || d->nsplit > 1 || (g->h & 7))) return DVD_E_ARG;
     if (d->frames <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Cout <= 0) return DVD_E_ARG;
@@ -1641,7 +1644,6 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     if (d->kt > 1 && d->up2) return DVD_E_SHAPE;
     const long long M = (long long)d->frames * d->T * d->H * d->W;
     if (M >= (1ll << 31) - BM) return DVD_E_SHAPE;
-    ConvK p;
     p.in = (const char*)d->in; p.w = (const char*)d->w; p.bias = d->bias; p.res = (const char*)d->res;
     p.mask = (const char*)d->mask; p.out = (char*)d->out; p.ws = d->ws;
     p.M = (int)M; p.C = d->C; p.ldi = d->ldi; p.Cout = d->Cout; p.ldo = d->ldo; p.ldres = d->ldres; p.ldmask = d->ldmask;
@@ -1693,6 +1695,16 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;
     const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= big_thr;   // >= 2 workgroups per CU
+    pl.M = M; pl.halo = halo; pl.thin = thin; pl.wide = wide; pl.big = big;
+    return DVD_OK;
+}
+
+extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream) {
+    ConvK p; ConvPlan pl;
+    const int rc = conv_plan(d, g, p, pl);
+    if (rc != DVD_OK) return rc;
+    const long long M = pl.M;
+    const bool halo = pl.halo, thin = pl.thin, wide = pl.wide, big = pl.big;
     dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
