@@ -224,14 +224,25 @@ def main():
 
     roof = None
     if not a.no_kernel_prof:
-        lib.dvd_prof_report.restype = C.c_longlong
-        res = {}
+        lib.dvd_prof_report_variants.restype = C.c_longlong
+        res, by_kernel = {}, {}
+        vnames = {0: {1: "conv_halo_kernel<bf16, 256x128 tile>", 2: "conv_halo_kernel<bf16, 128x128 tile>",
+                      3: "conv_halo_kernel<bf16, 256x64 tile>", 4: "conv_igemm_kernel<bf16, 128x128 tile>",
+                      5: "conv_igemm_kernel<bf16, 256x128 tile>", 6: "conv_igemm_kernel<bf16, 256x256 tile, 8 waves>"},
+                  1: {1: "conv_wgrad_row_kernel", 2: "conv_wgrad_kernel"}}
         for kind, name in ((0, "conv_igemm"), (1, "conv_wgrad")):
-            tms, fl = C.c_double(), C.c_double()
-            n = lib.dvd_prof_report(kind, C.byref(tms), C.byref(fl))     # totals of the instrumented (last timed) step
-            res[name] = {"launches": int(n), "ms": tms.value,
-                         "tflops": (fl.value / (tms.value * 1e-3) / 1e12) if tms.value else 0.0,
-                         "avg_us": tms.value * 1e3 / max(n, 1), "gflop_per_launch": fl.value / max(n, 1) / 1e9}
+            NV = 8
+            nn, tms, fl = (C.c_longlong * NV)(), (C.c_double * NV)(), (C.c_double * NV)()
+            lib.dvd_prof_report_variants(kind, NV, nn, tms, fl)          # totals of the instrumented step, per kernel variant
+            mk = lambda v: {"launches": int(nn[v]), "ms": tms[v],
+                            "tflops": (fl[v] / (tms[v] * 1e-3) / 1e12) if tms[v] else 0.0,
+                            "avg_us": tms[v] * 1e3 / max(nn[v], 1), "gflop_per_launch": fl[v] / max(nn[v], 1) / 1e9}
+            res[name] = mk(0)
+            for v, vn in vnames[kind].items():
+                if nn[v]:
+                    e = mk(v)
+                    by_kernel[vn] = {"launches": e["launches"], "ms": round(e["ms"], 1), "avg_us": round(e["avg_us"], 1),
+                                     "achieved": round(e["tflops"], 1)}
         F = F_GFLOP_PER_CLIP.get((a.ch, a.frames, a.size))
         dom = res["conv_igemm"]
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -241,6 +252,7 @@ def main():
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),
                 "gflop_per_launch": round(dom["gflop_per_launch"], 2), "kernel_ms_per_step": round(dom["ms"], 1),
                 "wgrad": {k: round(v, 2) if isinstance(v, float) else v for k, v in res["conv_wgrad"].items()},
+                "kernels": {k: dict(v, frac=round(v["achieved"] / peak, 4)) for k, v in by_kernel.items()},
                 "timing": "HIP events on the launch stream around each launch of one extra step after the timed region, kernels serialised (no concurrent weight-gradient stream) in that step",
                 "step_achieved": round(value / world * F / 1e3, 1) if F else None,
                 "step_frac": round(value / world * F / 1e3 / peak, 4) if F else None}

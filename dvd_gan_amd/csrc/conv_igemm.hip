@@ -39,6 +39,14 @@ template <typename T> __device__ __forceinline__ u32x4 relu16(u32x4 v);
 template <> __device__ __forceinline__ u32x4 relu16<float>(u32x4 v) { return relu16_f32(v); }
 template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) { return relu16_bf16(v); }
 
+// row index of a [frames][H][W] grid -> (frame, y, x).  Power-of-two extents (every size the 64 x 64 / 128 x 128 models
+// produce) take shifts; any other extent (latent_dim 3, 6, ...: logW < 0) takes divisions -- those sizes run through the
+// tap-by-tap kernels only, where the decomposition is outside the K loop (forward) or the launch is small.
+__device__ __forceinline__ void grid_pos(int m, int H, int W, int logH, int logW, int& f, int& y, int& x) {
+    if (logW >= 0) { x = m & (W - 1); y = (m >> logW) & (H - 1); f = m >> (logW + logH); }
+    else { f = m / (H * W); const int r = m - f * (H * W); y = r / W; x = r - y * W; }
+}
+
 // ============================================================================ forward
 struct ConvK {
     const char* in; const char* w; const float* bias; const char* res; const char* mask;
@@ -396,7 +404,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
     for (int k = 0; k < 8; ++k) bias8[k] = (p.bias && k < nvalid) ? p.bias[col + k] : 0.f;
     const bool has_mask = p.mask != nullptr;
     // the residual of a res_up2 conv lives on the half-size grid; its descriptor starts at the tile's first frame there
-    const long long res_row0 = p.res_up2 ? ((row0 >> (p.logW + p.logH)) << (p.logW + p.logH - 2)) : row0;
+    const long long res_row0 = p.res_up2 ? (row0 / (p.H * p.W)) * ((p.H >> 1) * (p.W >> 1)) : row0;
     const auto rres = epi_rsrc(p.res, res_row0, p.ldres * esz, (p.res_up2 ? (long long)(p.M >> 2) : (long long)p.M) - res_row0);
     const auto rmask = epi_rsrc(p.mask, row0, p.ldmask * esz, rows);
     const auto rout = epi_rsrc(p.out, row0, p.ldo * (p.out_f32 ? 4u : esz), rows);
@@ -407,8 +415,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
             mv[i % (D + 1)] = bld8<T>(rmask, offs(rr, p.ldmask, esz, col, colv));
             if (p.res_up2 && rr >= 0) {            // residual kept at H/2 x W/2: nearest x2 while reading
                 const int row = (int)row0 + rr;
-                const int x = row & (p.W - 1), y = (row >> p.logW) & (p.H - 1), f = row >> (p.logW + p.logH);
-                rr = (f << (p.logW + p.logH - 2)) + ((y >> 1) << (p.logW - 1)) + (x >> 1) - (int)res_row0;
+                int f, y, x;
+                grid_pos(row, p.H, p.W, p.logH, p.logW, f, y, x);
+                rr = (f * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1) - (int)res_row0;
             }
             resv[i % (D + 1)] = bld8<T>(rres, offs(rr, p.ldres, esz, col, colv));
         },
@@ -490,8 +499,9 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + (i * NWAVE + wu) * 16 + lrow;
         am[i] = m; av[i] = m < p.M;
-        ax[i] = m & (p.W - 1); ay[i] = (m >> p.logW) & (p.H - 1);
-        at[i] = p.kt > 1 ? (m >> (p.logW + p.logH)) % p.T : 0;
+        int f_;
+        grid_pos(m, p.H, p.W, p.logH, p.logW, f_, ay[i], ax[i]);
+        at[i] = p.kt > 1 ? f_ % p.T : 0;
     }
     int cob[NB];
     bool cov[NB];
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     // Offsets are 32-bit, activations can exceed 4 GiB: the descriptor of the activation tensor starts
     // at the first input row this tile can touch (wave-uniform), offsets are relative to it.
     const unsigned ldb = (unsigned)p.ldi * (unsigned)esz;        // input row pitch in bytes
-    const int base_row = p.up2 ? (m0 >> (p.logW + p.logH)) * p.Hin * p.Win : max(0, m0 - p.maxshift);
+    const int base_row = p.up2 ? (m0 / (p.H * p.W)) * p.Hin * p.Win : max(0, m0 - p.maxshift);
     const size_t base_b = (size_t)base_row * ldb;
     const size_t left_b = p.in_bytes - base_b;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
                              (unsigned)tt_ < (unsigned)p.T;
             unsigned off_ = aoff[i] + udelta_;
             if (p.up2) {
-                const int f_ = am[i] >> (p.logW + p.logH);
+                const int f_ = p.logW >= 0 ? am[i] >> (p.logW + p.logH) : am[i] / (p.H * p.W);
                 off_ = (unsigned)(((f_ + dt_) * p.Hin + (yy_ >> 1)) * p.Win + (xx_ >> 1) - base_row) * ldb + cc * 64 + q * 16;
             }
             dma16(rin, abase_ + i * (NWAVE * 1024), ok_ ? off_ : 0xffffffffu);
@@ -963,7 +973,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
     // Buffer descriptors: invalid rows / channels use offset 0xFFFFFFFF -> hardware returns zeros.
     // (32-bit offsets relative to the first row this workgroup's row slice can touch: tensors > 4 GiB ok)
     constexpr unsigned ESZ = sizeof(T);
-    const int xbase_row = p.up2 ? (m_begin >> (p.logW + p.logH)) * p.Hin * p.Win : max(0, m_begin - p.maxshift);
+    const int xbase_row = p.up2 ? (m_begin / (p.H * p.W)) * p.Hin * p.Win : max(0, m_begin - p.maxshift);
     const size_t xbase_b = (size_t)xbase_row * p.ldx * ESZ, ybase_b = (size_t)m_begin * p.ldy * ESZ;
     const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -974,13 +984,15 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
     // the output grid, so the shifted row is simply m + delta.
     const int delta = (dt * p.H + dy_) * p.W + dx;
     auto xoff = [&](int m, unsigned chan_bytes, bool cvalid) __attribute__((always_inline)) -> unsigned {
-        const int xx = (m & (p.W - 1)) + dx, yy = ((m >> p.logW) & (p.H - 1)) + dy_;
+        int fm, ym, xm;
+        grid_pos(m, p.H, p.W, p.logH, p.logW, fm, ym, xm);
+        const int xx = xm + dx, yy = ym + dy_;
         int tt = dt;
-        if (p.kt > 1) tt += (m >> (p.logW + p.logH)) % p.T;
+        if (p.kt > 1) tt += fm % p.T;
         const bool ok = cvalid && m < m_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W &&
                         (unsigned)tt < (unsigned)p.T;
         int row = m + delta;
-        if (p.up2) row = (((m >> (p.logW + p.logH)) + dt) * p.Hin + (yy >> 1)) * p.Win + (xx >> 1);
+        if (p.up2) row = ((fm + dt) * p.Hin + (yy >> 1)) * p.Win + (xx >> 1);
         return ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * ESZ) + chan_bytes : 0xffffffffu;
     };
     auto yoff = [&](int m, unsigned chan_bytes, bool cvalid) __attribute__((always_inline)) -> unsigned {
@@ -1580,7 +1592,7 @@ __global__ void pack_weight_kernel(PackK p) {
 #include <cstdio>
 #include <cstdlib>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int kind; long long M; int C, Cout, taps, split, flags; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; long long M; int C, Cout, taps, split, flags, variant; };
 bool g_prof = false;
 std::vector<ProfRec> g_recs;
 std::mutex g_prof_mu;
@@ -1590,6 +1602,7 @@ struct ProfScope {
         : on(g_prof), s((hipStream_t)stream) {
         if (!on) return;
         r.kind = kind; r.flops = flops; r.M = M; r.C = C; r.Cout = Cout; r.taps = taps; r.split = split; r.flags = flags;
+        r.variant = 0;
         hipEventCreate(&r.a); hipEventCreate(&r.b);
         hipEventRecord(r.a, s);
     }
@@ -1605,11 +1618,15 @@ extern "C" void dvd_prof_enable(int on) {
     std::lock_guard<std::mutex> l(g_prof_mu);
     g_prof = on != 0;
 }
-// kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Returns the number of launches.
+// kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Drains the records of `kind` and returns the number of
+// launches; n / ms / flops (each [nvar] or NULL) receive the per-variant totals -- kind 0: 1 = conv_halo 256 x 128,
+// 2 = conv_halo 128 x 128, 3 = conv_halo 256 x 64 (thin outputs), 4 = conv_igemm 128 x 128, 5 = conv_igemm 256 x 128,
+// 6 = conv_igemm 256 x 256 (8 waves); kind 1: 1 = filter-row kernel, 2 = one-tap kernel; index 0 = everything.
 // If the environment variable DVD_PROF_CSV is set, every drained record is appended to that file.
-extern "C" long long dvd_prof_report(int kind, double* total_ms, double* total_flops) {
+extern "C" long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops) {
     std::lock_guard<std::mutex> l(g_prof_mu);
-    double ms = 0, fl = 0; long long n = 0;
+    for (int v = 0; v < nvar; ++v) { if (n) n[v] = 0; if (ms) ms[v] = 0; if (flops) flops[v] = 0; }
+    long long total = 0;
     std::vector<ProfRec> keep;
     const char* csv = getenv("DVD_PROF_CSV");
     FILE* f = csv ? fopen(csv, "a") : nullptr;
@@ -1618,14 +1635,24 @@ extern "C" long long dvd_prof_report(int kind, double* total_ms, double* total_f
         hipEventSynchronize(r.b);
         float t = 0; hipEventElapsedTime(&t, r.a, r.b);
         if (f) fprintf(f, "%d,%lld,%d,%d,%d,%d,%d,%.4f,%.0f\n", r.kind, r.M, r.C, r.Cout, r.taps, r.split, r.flags, t, r.flops);
-        ms += t; fl += r.flops; ++n;
+        const int slots[2] = {0, r.variant};                    // slot 0 = all launches, plus the record's own slot
+        for (int j = 0; j < (r.variant > 0 ? 2 : 1); ++j) {
+            const int v = slots[j];
+            if (v >= nvar) continue;
+            if (n) ++n[v];
+            if (ms) ms[v] += t;
+            if (flops) flops[v] += r.flops;
+        }
+        ++total;
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
     if (f) fclose(f);
     g_recs.swap(keep);
-    if (total_ms) *total_ms = ms;
-    if (total_flops) *total_flops = fl;
-    return n;
+    return total;
+}
+extern "C" long long dvd_prof_report(int kind, double* total_ms, double* total_flops) {
+    long long n = 0;
+    return dvd_prof_report_variants(kind, 1, &n, total_ms, total_flops);
 }
 
 // ============================================================================ C ABI
@@ -1637,8 +1664,9 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     if (!d || !d->in || !d->w || (!d->ws && (!d->out || d->nsplit > 1))) return DVD_E_ARG;
     if (g && (d->ws || d->nsplit > 1 || (g->h & 7))) return DVD_E_ARG;
     if (d->frames <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Cout <= 0) return DVD_E_ARG;
-    const int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
-    if (logH < 0 || logW < 0) return DVD_E_SHAPE;
+    int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
+    const bool pow2 = logH >= 0 && logW >= 0;
+    if (!pow2) logH = logW = -1;           // any other extent: division-based indexing in the tap-by-tap kernels (grid_pos)
     if ((d->C & 7) || (d->ldi & 7) || !(d->kt & d->kh & d->kw & 1)) return DVD_E_SHAPE;
     if (d->up2 && ((d->H | d->W) & 1)) return DVD_E_SHAPE;
     if (d->kt > 1 && d->up2) return DVD_E_SHAPE;
@@ -1648,7 +1676,7 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     p.mask = (const char*)d->mask; p.out = (char*)d->out; p.ws = d->ws;
     p.M = (int)M; p.C = d->C; p.ldi = d->ldi; p.Cout = d->Cout; p.ldo = d->ldo; p.ldres = d->ldres; p.ldmask = d->ldmask;
     p.res_up2 = d->res && d->res_up2;
-    if (p.res_up2 && (d->H < 2 || d->W < 2)) return DVD_E_SHAPE;
+    if (p.res_up2 && (d->H < 2 || d->W < 2 || ((d->H | d->W) & 1))) return DVD_E_SHAPE;
     p.T = d->T; p.H = d->H; p.W = d->W; p.logH = logH; p.logW = logW;
     p.Hin = d->up2 ? d->H / 2 : d->H; p.Win = d->up2 ? d->W / 2 : d->W;
     p.kt = d->kt; p.kh = d->kh; p.kw = d->kw;
@@ -1666,7 +1694,7 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     // 4-wave workgroups only: with the activation DMAs gone, two 256 x 128 workgroups per CU beat one 8-wave
     // 256 x 256 workgroup (1.13-1.34 vs 0.86-1.12 PF/s on the S = 16 / 32 shapes of config C2).
     static const int use_halo = getenv("DVD_CONV_HALO") ? atoi(getenv("DVD_CONV_HALO")) : 1;
-    const bool halo = use_halo && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->W >= 16 && d->H >= 16 &&
+    const bool halo = use_halo && pow2 && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->W >= 16 && d->H >= 16 &&
                       p.nsplit <= p.kchunks * d->kt;
     const bool thin = halo && d->dtype == DVD_BF16 && d->Cout <= 64 && cdiv(M, 256) * (long long)p.nsplit >= 512;
     const bool wide = !halo && d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
@@ -1709,6 +1737,7 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
     hipStream_t st = (hipStream_t)stream;
+    prof.r.variant = halo ? (thin ? 3 : big ? 1 : 2) : (wide ? 6 : big ? 5 : 4);
     if (halo) {
 #define LAUNCH_HALO2(TT, TM_, WN_, RL_)                                                             \
         do { if (d->up2) conv_halo_kernel<TT, TM_, WN_, RL_, true><<<grid, 128 * WN_, 0, st>>>(p);      \
@@ -1748,8 +1777,10 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
 // mode: 0 = one tap per workgroup (conv_wgrad_kernel), 1 = one filter row per workgroup (conv_wgrad_row_kernel; ta = WM)
 static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit, int& mode) {
     if (!d || !d->x || !d->dy || !d->dw) return DVD_E_ARG;
-    const int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
-    if (logH < 0 || logW < 0) return DVD_E_SHAPE;
+    int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
+    const bool pow2 = logH >= 0 && logW >= 0;
+    if (!pow2) logH = logW = -1;           // division-based indexing, one-tap kernel only
+    if (d->up2 && ((d->H | d->W) & 1)) return DVD_E_SHAPE;
     if ((d->C & 7) || (d->ldx & 7) || (d->Cy & 7) || (d->ldy & 7) || !(d->kt & d->kh & d->kw & 1)) return DVD_E_SHAPE;
     if (d->Cout > d->Cy || d->Cin_real > d->C) return DVD_E_ARG;
     if (d->dtype != DVD_BF16 && d->dtype != DVD_F32) return DVD_E_ARG;
@@ -1767,7 +1798,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         else if (d->Cin_real >= 192) tb = 4;
     }
     static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
-    mode = (use_row && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) && d->W >= 8 &&
+    mode = (use_row && pow2 && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) && d->W >= 8 &&
             (d->H * d->W) % 32 == 0) ? 1 : 0;
     if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
         const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
@@ -1842,6 +1873,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
+    prof.r.variant = mode == 1 ? 1 : 2;
     if (mode == 1) {
 #define LAUNCH_ROW(WM_, KW_)                                                                        \
         do { if (d->relu_in) conv_wgrad_row_kernel<WM_, KW_, true><<<grid, WM_ * 128, 0, st>>>(p);      \

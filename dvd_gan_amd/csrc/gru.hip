@@ -85,7 +85,7 @@ __global__ void gru_gates_ur_kernel(const float* ws, int ns, const T* gx, int ld
         hp[k] = hprev ? hp[k] * pr[k] : 0.f;
     }
     store8<T>(u + (size_t)row * h + c, pu);
-    store8<T>(r + (size_t)row * h + c, pr);
+    if (r) store8<T>(r + (size_t)row * h + c, pr);           // (not kept by an inference-mode forward)
     store8<T>(hr + (size_t)row * h + c, hp);
 }
 
@@ -113,7 +113,7 @@ __global__ void gru_out_kernel(const float* ws, int ns, const T* gx, int ldg, co
         po[k] = round_to<T>(gate_tanh<T>(po[k]));
         hp[k] = hp[k] * (1.f - uu[k]) + po[k] * uu[k];
     }
-    store8<T>(o + (size_t)row * h + c, po);
+    if (o) store8<T>(o + (size_t)row * h + c, po);
     store8<T>(hn + (size_t)row * h + c, hp);
     if (h32n) store8<float>(h32n + (size_t)row * h + c, hp);
 }
@@ -196,7 +196,7 @@ int conv_fused(int dtype, int B, int H, int W, int k, const void* in, int C, con
                void* stream) {
     dvd_conv_desc d = {};
     d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = C; d.Cout = Cout; d.ldo = Cout;
-    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.out = g.mode == 1 ? g.u : g.o;
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.out = g.mode == 1 ? g.u : g.hn;   // (`out` itself is not written)
     return dvd_conv_forward_gru(&d, &g, stream);
 }
 
@@ -252,23 +252,26 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
 }
 
 extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
-    if (!d || !d->gx || !d->w_ur || !d->w_o || !d->h_all || !d->u_all || !d->r_all || !d->o_all || !d->hr_all || !d->ws)
-        return DVD_E_ARG;
+    if (!d || !d->gx || !d->w_ur || !d->w_o || !d->h_all || !d->u_all || !d->hr_all || !d->ws) return DVD_E_ARG;
+    if (!d->infer && (!d->r_all || !d->o_all)) return DVD_E_ARG;
     if (d->T <= 0 || d->B <= 0 || d->hidden <= 0 || !(d->k & 1)) return DVD_E_ARG;
     if (d->hidden & 7) return DVD_E_SHAPE;
+    const int t_lo = d->t_end > 0 ? d->t_begin : 0, t_hi = d->t_end > 0 ? d->t_end : d->T;
+    if (t_lo < 0 || t_hi > d->T || t_lo >= t_hi) return DVD_E_ARG;
     const int h = d->hidden, ntaps = d->k * d->k;
     const long long M = (long long)d->B * d->H * d->W;
     if (M * (d->hidden / 8) >= (1ll << 31)) return DVD_E_SHAPE;
     const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
     const size_t step = (size_t)M * h * esz;
+    const size_t astep = d->infer ? 0 : step;       // inference: u / h*r are one-step scratch, r and o are not stored at all
     const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, 2 * h, h, ntaps);
     const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);
     const unsigned grid = cdiv(M * (h / 8), 256);
-    for (int t = 0; t < d->T; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         const char* hprev = t > 0 ? (const char*)d->h_all + (t - 1) * step : (const char*)d->h0;
         const char* gx = (const char*)d->gx + (size_t)t * d->gx_stride * esz;
-        char* u = (char*)d->u_all + t * step; char* r = (char*)d->r_all + t * step;
-        char* o = (char*)d->o_all + t * step; char* hr = (char*)d->hr_all + t * step;
+        char* u = (char*)d->u_all + t * astep; char* r = d->infer ? nullptr : (char*)d->r_all + t * step;
+        char* o = d->infer ? nullptr : (char*)d->o_all + t * step; char* hr = (char*)d->hr_all + t * astep;
         char* hn = (char*)d->h_all + t * step;
         const float* h32p = (d->h32 && t > 0) ? d->h32 + (size_t)(t & 1) * M * h : nullptr;
         float* h32n = d->h32 ? d->h32 + (size_t)((t + 1) & 1) * M * h : nullptr;

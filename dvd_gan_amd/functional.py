@@ -312,7 +312,10 @@ class ConvGRULayer(Function):
     Returns h for every step as [T*B,S,S,hidden]."""
 
     @staticmethod
-    def forward(ctx, x, wu, bu, wr, br, wo, bo, T, shared_x, h0):
+    def forward(ctx, x, wu, bu, wr, br, wo, bo, T, shared_x, h0, infer=False):
+        """infer (the caller runs under torch.no_grad(): the sampling path, trainer.py:323-334): nothing is kept for a
+        backward pass -- u and h*r live in one-step scratch buffers, r and o are not stored at all (4 of the 5 [T, ...] tensors
+        of the training forward are never allocated, a seventh of the gate epilogues' traffic is not written)."""
         dev, dtype = x.device, x.dtype
         hid, ctot, k = wu.shape[0], wu.shape[1], wu.shape[-1]
         cin = ctot - hid
@@ -328,8 +331,11 @@ class ConvGRULayer(Function):
         po.fill(wo, ci_off=cin)
         bias3 = torch.cat([bu, br, bo])
         gx = K.conv_forward(x, px.wf, (k, k), 3 * hid, bias=bias3)
-        mk = lambda: torch.empty(T, B, S1, S2, hid, dtype=dtype, device=dev)
-        h_all, u_all, r_all, o_all, hr_all = mk(), mk(), mk(), mk(), mk()
+        mk = lambda n=T: torch.empty(n, B, S1, S2, hid, dtype=dtype, device=dev)
+        if infer:
+            h_all, u_all, hr_all, r_all, o_all = mk(), mk(1), mk(1), None, None
+        else:
+            h_all, u_all, r_all, o_all, hr_all = mk(), mk(), mk(), mk(), mk()
         h32 = torch.empty(2, M, hid, dtype=torch.float32, device=dev) if dtype != torch.float32 else None
         lib = L.lib()
         ntaps = k * k
@@ -342,11 +348,15 @@ class ConvGRULayer(Function):
         d.gx_stride = 0 if shared_x else M * 3 * hid
         d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
         d.h0 = h0.data_ptr() if h0 is not None else None
-        d.h_all, d.u_all, d.r_all = h_all.data_ptr(), u_all.data_ptr(), r_all.data_ptr()
-        d.o_all, d.hr_all = o_all.data_ptr(), hr_all.data_ptr()
+        d.h_all, d.u_all, d.hr_all = h_all.data_ptr(), u_all.data_ptr(), hr_all.data_ptr()
+        d.r_all = r_all.data_ptr() if r_all is not None else None
+        d.o_all = o_all.data_ptr() if o_all is not None else None
         d.h32 = h32.data_ptr() if h32 is not None else None
         d.ws = ws.data_ptr()
+        d.infer = int(infer)
         L.check(lib.dvd_convgru_layer_forward(C.byref(d), L.stream()))
+        if infer:
+            return h_all.view(T * B, S1, S2, hid)
         ctx.save_for_backward(x, wu, wr, wo, h_all, u_all, r_all, o_all, hr_all, h0)
         ctx.params = (wu, bu, wr, br, wo, bo)
         ctx.packs = (px, pur, po)
@@ -416,7 +426,7 @@ class ConvGRULayer(Function):
         dh0 = None
         if dh0_32 is not None:
             dh0 = dh0_32.view(h0.shape) if h0.dtype == torch.float32 else K.convert(dh0_32, h0.dtype).view(h0.shape)
-        return (dx, grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2], None, None, dh0)
+        return (dx, grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2], None, None, dh0, None)
 
 
 # ------------------------------------------------------------------ attention / head / loss

@@ -35,7 +35,8 @@ class ConvGRUCell(nn.Module):
 
     def run(self, x, T, shared_x, h0=None):
         return Fn.ConvGRULayer.apply(x, self.update_gate.weight, self.update_gate.bias, self.reset_gate.weight,
-                                     self.reset_gate.bias, self.out_gate.weight, self.out_gate.bias, T, shared_x, h0)
+                                     self.reset_gate.bias, self.out_gate.weight, self.out_gate.bias, T, shared_x, h0,
+                                     not torch.is_grad_enabled())
 
 
 class ConvGRU(nn.Module):
@@ -104,9 +105,10 @@ class Generator(nn.Module):
         if ch < 2 or ch % 2:
             raise ValueError(f"ch={ch}: the ConvGRU kernels keep hidden states in 16-byte channel vectors, so the smallest "
                              "hidden size 4*ch must be a multiple of 8 (ch even)")
-        if latent_dim < 1 or latent_dim & (latent_dim - 1):
-            raise ValueError(f"latent_dim={latent_dim}: the HIP convolution kernels index frames with shifts, so every "
-                             "stage size (latent_dim * 2^k) must be a power of two (4 -> 64x64, 8 -> 128x128 clips)")
+        if latent_dim < 1:
+            raise ValueError(f"latent_dim={latent_dim}")
+        # (power-of-two latent_dim -- 4 -> 64x64, 8 -> 128x128 clips -- runs the LDS-staged kernels; any other value, e.g. 3 or 6
+        #  -> 48x48 / 96x96, the tap-by-tap kernels with division indexing: same results, lower throughput)
         self.in_dim, self.latent_dim, self.n_class, self.ch, self.n_frames = in_dim, latent_dim, n_class, ch, n_frames
         self.hierar_flag = hierar_flag
         self.compute_dtype = compute_dtype

@@ -9,7 +9,8 @@
  *     (a hipStream_t passed as void*), never synchronises the device, keeps no global state;
  *   - return value: 0 = ok, <0 = DVD_E_* (bad argument / unsupported shape / launch failure);
  *   - activations are channels-last: [frames][T][H][W][C] with C padded to a multiple of 8,
- *     row stride `ld*` in ELEMENTS; spatial extents H, W must be powers of two;
+ *     row stride `ld*` in ELEMENTS; spatial extents H, W: powers of two take the fast kernels (LDS-staged footprints,
+ *     shift indexing), any other extent (latent_dim 3, 6, ... of Generator.py:15) the tap-by-tap kernels with division indexing;
  *   - `dtype` selects the STORAGE / MFMA operand type of activations and packed weights:
  *     DVD_F32 (exact mode, v_mfma_f32_32x32x2_f32) or DVD_BF16 (v_mfma_f32_32x32x16_bf16);
  *     accumulation, statistics, master weights, gradients of weights are always fp32.
@@ -26,7 +27,7 @@ extern "C" {
 
 #define DVD_OK 0
 #define DVD_E_ARG (-1)      /* null pointer / non-positive size                                */
-#define DVD_E_SHAPE (-2)    /* unsupported shape (C % 8, non power-of-two H/W, even kernel...) */
+#define DVD_E_SHAPE (-2)    /* unsupported shape (C % 8, even kernel, odd extent under a x2 upsample ...) */
 #define DVD_E_LAUNCH (-3)   /* hipGetLastError() != hipSuccess after a launch                  */
 
 #define DVD_ACT_NONE 0
@@ -40,6 +41,10 @@ int dvd_abi_version(void);              /* bumps when a signature changes       
  * returns the launch count, total milliseconds and total algorithmic FLOPs (2*M*Cout*C*taps). */
 void dvd_prof_enable(int on);
 long long dvd_prof_report(int kind, double* total_ms, double* total_flops);
+/* The same, split by kernel variant: n / ms / flops are arrays of nvar entries (or NULL); entry 0 = all launches of `kind`,
+ * kind 0: 1 = conv_halo 256x128 tile, 2 = conv_halo 128x128, 3 = conv_halo 256x64, 4 = conv_igemm 128x128,
+ * 5 = conv_igemm 256x128, 6 = conv_igemm 256x256; kind 1: 1 = filter-row kernel, 2 = one-tap kernel. */
+long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops);
 const char* dvd_strerror(int code);
 
 /* ------------------------------------------------------------------------------------------
@@ -158,6 +163,11 @@ typedef struct {
     void* dg;                  /* out [T][M][3*hidden]                                           */
     float* carry;              /* scratch [M][hidden] fp32                                       */
     float* dh0;                /* optional out [M][hidden] fp32: gradient wrt h0                 */
+    /* forward only */
+    int t_begin, t_end;        /* t_end > 0: only steps [t_begin, t_end) of the T steps are run by this call (a caller that
+                                  feeds gx chunk by chunk); step t_begin - 1 must have been run before.  0, 0 = all steps   */
+    int infer;                 /* 1 (sampling path, trainer.py:323-334: no backward will follow): u_all / hr_all are ONE-step
+                                  scratch buffers [M][hidden], r and o are not stored (r_all, o_all may be NULL)           */
 } dvd_gru_desc;
 int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream);
 int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream);

@@ -68,6 +68,13 @@ CASES = [
     (3, 72, 200, (16, 16), (3, 3), False, True),     # W = 16: two lines + 2, two in-channel tiles, ReLU
     (2, 24, 72, (16, 64), (3, 3), False, False),     # W = 64: two 32-pixel segments per line, H != W
     (1, 72, 136, (6, 8, 16), (3, 3, 3), False, False),   # 3-D, T = 6
+    # extents that are not powers of two (latent_dim 3 / 6: 6, 12, 24, 48, 96 pixels): division indexing, tap-by-tap kernels
+    (3, 16, 24, (6, 6), (3, 3), False, False),
+    (2, 24, 40, (12, 12), (5, 5), False, True),
+    (2, 16, 40, (24, 12), (3, 3), True, True),           # x2 upsample folded in, H != W
+    (5, 40, 264, (6, 6), (5, 5), False, False),          # wide N, ragged M
+    (1, 8, 16, (3, 6, 6), (3, 3, 3), False, False),      # 3-D
+    (2, 24, 72, (48, 48), (3, 3), False, False),         # a multiple of 16 that is not a power of two
 ]
 
 
@@ -144,7 +151,8 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(3, 16, 40, (16, 16), (3, 3)), (2, 8, 24, (4, 8, 8), (3, 3, 3)), (5, 24, 8, (32, 32), (1, 1))])
+@pytest.mark.parametrize("shape", [(3, 16, 40, (16, 16), (3, 3)), (2, 8, 24, (4, 8, 8), (3, 3, 3)), (5, 24, 8, (32, 32), (1, 1)),
+                                   (3, 16, 24, (12, 12), (3, 3)), (2, 8, 8, (6, 24), (1, 1))])
 def test_residual_read_through_nearest_upsample(shape, dtype):
     """res_up2: the residual operand lives on the H/2 x W/2 grid and is expanded (nearest x2) in the epilogue --
     out = conv(x) + b + upsample(res)."""
@@ -169,10 +177,13 @@ def test_residual_read_through_nearest_upsample(shape, dtype):
 
 def test_bad_shapes_raise():
     from dvd_gan_amd import kern as K
-    x = torch.zeros(1, 6, 8, 8, device="cuda")          # H=6 is not a power of two
+    x = torch.zeros(1, 5, 8, 8, device="cuda")          # an odd extent cannot be the output of a x2 upsample
     pk = K.PackedConv(torch.float32, 8, 8, (3, 3), "cuda")
     with pytest.raises(RuntimeError):
-        K.conv_forward(x, pk.wf, (3, 3), 8)
+        K.conv_forward(torch.zeros(1, 5, 4, 8, device="cuda"), pk.wf, (3, 3), 8, res=x, res_up2=True)
+    pk2 = K.PackedConv(torch.float32, 8, 8, (2, 2), "cuda")     # even filter
+    with pytest.raises(RuntimeError):
+        K.conv_forward(torch.zeros(1, 8, 8, 8, device="cuda"), pk2.wf, (2, 2), 8)
 
 
 def test_f32_to_bf16_is_round_to_nearest_even():

@@ -532,3 +532,36 @@ def test_generator_attention_flags_vs_oracle():
         # ch=2 end-to-end fixture (see GEN_TOL): rounding is amplified ~100x, the gamma gradients are sums over the whole
         # clip with heavy cancellation
         assert rel(dict(G.named_parameters())[name].grad, sd[name].grad) < 5e-2, name
+
+
+@pytest.mark.parametrize("ld,dtype", [(3, torch.float32), (6, torch.float32), (6, torch.bfloat16)])
+def test_generator_with_latent_dim_that_is_not_a_power_of_two(ld, dtype):
+    """Generator(latent_dim=3 / 6) -> 48 x 48 / 96 x 96 clips (Generator.py:15,27,77 builds any latent_dim): stage sizes
+    3..48 / 6..96 take the division-indexed tap-by-tap kernels.  Exact mode against the oracle: clips and named parameter
+    gradients; bf16 mode: clips within the generator tolerance of the 64 x 64 fixtures."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.gen_net import Generator
+    torch.manual_seed(23)
+    ch, T, B, ncls, zd = 2, 4, 3, 3, 12
+    G = Generator(zd, ld, ncls, ch, T, compute_dtype=dtype)
+    sd = O.make_state({k: v.detach().clone() for k, v in G.state_dict().items()})
+    z, cls = torch.randn(B, zd), torch.randint(0, ncls, (B,))
+    want = O.generator(sd, z, cls, ch, T, latent_dim=ld)
+    assert want.shape == (B, T, 3, 16 * ld, 16 * ld)
+    gy = torch.randn_like(want)
+    want.backward(gy)
+    G = G.to(DEV).train()
+    got = G(z.to(DEV), cls.to(DEV))
+    assert got.shape == want.shape
+    if dtype == torch.bfloat16:
+        # default (orthogonal) initialisation: the free-running bf16 generator sits at the one-ulp sensitivity of the
+        # recurrence (tests/test_gpu_fullwidth.py, test_sensitivity_of_the_free_running_generator) -- this case only shows that
+        # the bf16 kernels serve these extents; the exact-mode cases carry the parity statement
+        assert torch.isfinite(got).all() and rel(got, want.detach()) < 0.35
+        return
+    assert rel(got, want.detach()) < 2e-4
+    got.backward(gy.to(DEV))
+    for name in ("conv.0.cells.0.update_gate.weight", "conv.3.cells.1.out_gate.weight", "conv.9.cells.2.reset_gate.weight",
+                 "conv.4.conv0.module.weight_bar", "conv.11.conv_sc.module.weight_bar", "conv.7.CBNorm1.embed.weight",
+                 "colorize.module.weight_bar", "affine_transfrom.weight"):
+        assert rel(dict(G.named_parameters())[name].grad, sd[name].grad) < 1e-2, name

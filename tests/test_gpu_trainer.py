@@ -396,3 +396,31 @@ def test_bf16_trajectory_follows_exact_mode(golden):
                    "displacement_cosine_G_Ds_Dt": cos, "exact_losses": he.tolist(), "bf16_losses": hb.tolist()}, f, indent=1)
     assert dev.max() < 1e-2, dev.max(0)
     assert min(cos) > 0.99, cos
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inference_forward_equals_training_forward_and_keeps_no_bptt_tensors(dtype):
+    """Trainer.sample() / any generator forward under torch.no_grad() takes the inference form of the ConvGRU layers (u and
+    h*r in one-step scratch buffers, r and o never stored): same clips bit for bit as the storing forward, a fraction of
+    its memory."""
+    from dvd_gan_amd.gen_net import Generator
+    torch.manual_seed(5)
+    G = Generator(16, 4, 3, 4, 8, compute_dtype=dtype).cuda().eval()
+    z, c = torch.randn(4, 16, device="cuda"), torch.randint(0, 3, (4,), device="cuda")
+    sd0 = {k: v.clone() for k, v in G.state_dict().items()}
+
+    def run(no_grad):
+        G.load_state_dict(sd0)                       # spectral-norm u / v advance with every forward (quirk 2)
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        if no_grad:
+            with torch.no_grad():
+                y = G(z, c)
+        else:
+            y = G(z, c)
+        torch.cuda.synchronize()
+        return y.detach().clone(), torch.cuda.max_memory_allocated() - base
+    y_train, mem_train = run(False)
+    y_infer, mem_infer = run(True)
+    assert torch.equal(y_train, y_infer)
+    assert mem_infer < 0.6 * mem_train, (mem_infer, mem_train)

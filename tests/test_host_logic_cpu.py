@@ -114,8 +114,9 @@ def test_argument_validation_messages():
     from dvd_gan_amd.gen_net import Generator
     from dvd_gan_amd.disc_nets import _check_frame_size
     from dvd_gan_amd.train_step import Trainer
-    with pytest.raises(ValueError, match="power of two"):
-        Generator(120, 6, 4, 2, 4)
+    with pytest.raises(ValueError, match="latent_dim"):
+        Generator(120, 0, 4, 2, 4)
+    Generator(120, 6, 4, 2, 4)                      # 96 x 96 clips: built (division-indexed kernels), tests/test_gpu_modules.py
     with pytest.raises(ValueError, match="power-of-two"):
         _check_frame_size(96, 96)
     with pytest.raises(ValueError, match="ch even"):
