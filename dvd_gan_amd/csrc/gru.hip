@@ -256,8 +256,6 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
     if (!d->infer && (!d->r_all || !d->o_all)) return DVD_E_ARG;
     if (d->T <= 0 || d->B <= 0 || d->hidden <= 0 || !(d->k & 1)) return DVD_E_ARG;
     if (d->hidden & 7) return DVD_E_SHAPE;
-    const int t_lo = d->t_end > 0 ? d->t_begin : 0, t_hi = d->t_end > 0 ? d->t_end : d->T;
-    if (t_lo < 0 || t_hi > d->T || t_lo >= t_hi) return DVD_E_ARG;
     const int h = d->hidden, ntaps = d->k * d->k;
     const long long M = (long long)d->B * d->H * d->W;
     if (M * (d->hidden / 8) >= (1ll << 31)) return DVD_E_SHAPE;
@@ -267,7 +265,7 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
     const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, 2 * h, h, ntaps);
     const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);
     const unsigned grid = cdiv(M * (h / 8), 256);
-    for (int t = t_lo; t < t_hi; ++t) {
+    for (int t = 0; t < d->T; ++t) {
         const char* hprev = t > 0 ? (const char*)d->h_all + (t - 1) * step : (const char*)d->h0;
         const char* gx = (const char*)d->gx + (size_t)t * d->gx_stride * esz;
         char* u = (char*)d->u_all + t * astep; char* r = d->infer ? nullptr : (char*)d->r_all + t * step;

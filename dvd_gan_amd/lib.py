@@ -82,4 +82,4 @@ class GruDesc(C.Structure):
                 ("h_all", C.c_void_p), ("u_all", C.c_void_p), ("r_all", C.c_void_p), ("o_all", C.c_void_p),
                 ("hr_all", C.c_void_p), ("h32", C.c_void_p), ("ws", C.c_void_p),
                 ("dh_out", C.c_void_p), ("dg", C.c_void_p), ("carry", C.c_void_p), ("dh0", C.c_void_p),
-                ("t_begin", C.c_int), ("t_end", C.c_int), ("infer", C.c_int)]
+                ("infer", C.c_int)]

@@ -164,8 +164,6 @@ typedef struct {
     float* carry;              /* scratch [M][hidden] fp32                                       */
     float* dh0;                /* optional out [M][hidden] fp32: gradient wrt h0                 */
     /* forward only */
-    int t_begin, t_end;        /* t_end > 0: only steps [t_begin, t_end) of the T steps are run by this call (a caller that
-                                  feeds gx chunk by chunk); step t_begin - 1 must have been run before.  0, 0 = all steps   */
     int infer;                 /* 1 (sampling path, trainer.py:323-334: no backward will follow): u_all / hr_all are ONE-step
                                   scratch buffers [M][hidden], r and o are not stored (r_all, o_all may be NULL)           */
 } dvd_gru_desc;
