@@ -322,9 +322,9 @@ class ConvGRULayer(Function):
         B = x.shape[0] if shared_x else x.shape[0] // T
         S1, S2 = x.shape[1], x.shape[2]
         M = B * S1 * S2
-        px = K.PackedConv(dtype, 3 * hid, cin, (k, k), dev)
-        pur = K.PackedConv(dtype, 2 * hid, hid, (k, k), dev)
-        po = K.PackedConv(dtype, hid, hid, (k, k), dev)
+        px = K.PackedConv(dtype, 3 * hid, cin, (k, k), dev, covered=True)     # the fills below write every output channel
+        pur = K.PackedConv(dtype, 2 * hid, hid, (k, k), dev, covered=True)
+        po = K.PackedConv(dtype, hid, hid, (k, k), dev, covered=True)
         for g, w in enumerate((wu, wr, wo)):
             px.fill(w, co_off=g * hid, ci_off=0)
         pur.fill(wu, co_off=0, ci_off=cin).fill(wr, co_off=hid, ci_off=cin)

@@ -60,15 +60,16 @@ def convert(src, dtype):
 class PackedConv:
     """Forward pack wf [ntaps][Cout_tot][Cip] and backward-data pack wd [ntaps][Cip][Cop]."""
 
-    def __init__(self, dtype, cout_tot, cin, ksize, device, need_dgrad=True, single_fill=False):
+    def __init__(self, dtype, cout_tot, cin, ksize, device, need_dgrad=True, single_fill=False, covered=False):
         """single_fill: ONE fill() call will cover all cout_tot output channels -- it writes every element of both
         images (zeros in the padded input channels) except the padded output columns of `wd`, so only a `wd` with
-        cout_tot % 8 != 0 needs the zero fill."""
+        cout_tot % 8 != 0 needs the zero fill.  covered: the caller's SEVERAL fill() calls together cover every output
+        channel (the fused gate packs of a ConvGRU layer): same consequence."""
         self.k = _ksize3(ksize)
         self.ntaps = self.k[0] * self.k[1] * self.k[2]
         self.cout, self.cin, self.cip, self.cop = cout_tot, cin, pad8(cin), pad8(cout_tot)
-        af = torch.empty if single_fill else torch.zeros
-        ad = torch.empty if (single_fill and self.cop == cout_tot) else torch.zeros
+        af = torch.empty if (single_fill or covered) else torch.zeros
+        ad = torch.empty if ((single_fill or covered) and self.cop == cout_tot) else torch.zeros
         self.wf = af(self.ntaps, cout_tot, self.cip, dtype=dtype, device=device)
         self.wd = ad(self.ntaps, self.cip, self.cop, dtype=dtype, device=device) if need_dgrad else None
 
