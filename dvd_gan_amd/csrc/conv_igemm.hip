@@ -56,6 +56,7 @@ struct ConvK {
     int kt, kh, kw, kchunks, nk, nsplit, tilesN;
     int up2, relu_in, act, out_f32;
     int nmajor;                          // tile order: consecutive workgroups (one XCD's run) share the N tile, not the M tile
+    int pm;                              // > 0 (tap-by-tap kernel, small frames): GEMM rows in PIXEL-major order, pm = frames (see conv_igemm_kernel)
     int dbg;                             // measurement aid (DVD_DBG_EPI): 1 = skip the epilogue (results are garbage), 2 = skip the main loop
     size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
     int maxshift;                        // largest |tap shift| in rows
@@ -479,9 +480,27 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     else { mt = bid / p.tilesN; nt = bid - mt * p.tilesN; }
     const int m0 = mt * BMt, n0 = nt * BNt;
     const int z = blockIdx.z;
-    const int per = (p.nk + p.nsplit - 1) / p.nsplit;
+    // Pixel-major row order (p.pm = frames F > 0; 4 x 4 / 8 x 8 recurrent convs): GEMM row m' = pixel * F + frame, so a tile
+    // holds a few pixels of ONE image line for many frames instead of whole frames -- every row of the tile then has the same
+    // set of filter rows that fall outside the frame (2 of 5 at the top / bottom line of a 5 x 5 conv: 30 % of all (line, row)
+    // pairs at 4 x 4, 15 % at 8 x 8), and those K steps are skipped for the whole tile instead of multiplying zeros.  The
+    // tensors keep their frame-major layout: only the row <-> workgroup assignment changes (memrow), results are identical.
+    const int HWp = p.H * p.W;
+    auto memrow = [&](int mp) __attribute__((always_inline)) -> int {
+        if (!p.pm) return mp;
+        const int px = mp / p.pm;
+        return (mp - px * p.pm) * HWp + px;
+    };
+    int iy_lo = 0, iy_hi = p.kh;                       // filter rows that touch the frame for this tile's image line
+    if (p.pm) {
+        const int y_t = (m0 / p.pm) >> p.logW, pad_ = p.kh >> 1;
+        iy_lo = max(0, pad_ - y_t); iy_hi = min(p.kh, p.H + pad_ - y_t);
+    }
+    const int ntaps = p.pm ? (iy_hi - iy_lo) * p.kw : p.kt * p.kh * p.kw;      // K steps per channel chunk
+    const int nk = ntaps * p.kchunks;
+    const int per = (nk + p.nsplit - 1) / p.nsplit;
     const int k_begin = z * per;
-    const int k_end = min(p.nk, k_begin + per);
+    const int k_end = min(nk, k_begin + per);
     const size_t esz = sizeof(T);
 
     // ---- staging: LDS-DMA (buffer_load ... lds).  One wave-instruction moves 64 x 16 B = 16 tile rows
@@ -497,8 +516,9 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     bool av[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + (i * NWAVE + wu) * 16 + lrow;
-        am[i] = m; av[i] = m < p.M;
+        const int mp = m0 + (i * NWAVE + wu) * 16 + lrow;
+        const int m = memrow(mp);
+        am[i] = m; av[i] = mp < p.M;
         int f_;
         grid_pos(m, p.H, p.W, p.logH, p.logW, f_, ay[i], ax[i]);
         at[i] = p.kt > 1 ? f_ % p.T : 0;
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     // Offsets are 32-bit, activations can exceed 4 GiB: the descriptor of the activation tensor starts
     // at the first input row this tile can touch (wave-uniform), offsets are relative to it.
     const unsigned ldb = (unsigned)p.ldi * (unsigned)esz;        // input row pitch in bytes
-    const int base_row = p.up2 ? (m0 / (p.H * p.W)) * p.Hin * p.Win : max(0, m0 - p.maxshift);
+    const int base_row = p.pm ? 0 : p.up2 ? (m0 / (p.H * p.W)) * p.Hin * p.Win : max(0, m0 - p.maxshift);
     const size_t base_b = (size_t)base_row * ldb;
     const size_t left_b = p.in_bytes - base_b;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
@@ -526,12 +546,15 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     // K order: channel chunk OUTER, taps INNER -- the 25 (9, 27) taps of one 64-byte channel chunk re-read
     // the same few input rows back to back, so they hit L1/L2 instead of coming back after a whole sweep
     // over C (which at 2 workgroups per CU is tens of MB per XCD, far beyond its 4 MiB L2).
-    const int ntaps = p.kt * p.kh * p.kw;
-    int tap = 0, cc = 0, it = 0, iy = 0, ix = 0;
+    int tap = 0, cc = 0, it = 0, iy = iy_lo, ix = 0;       // tap = index into the weight pack: (it * kh + iy) * kw + ix
     if (k_begin < k_end) {
-        cc = k_begin / ntaps; tap = k_begin - cc * ntaps;
-        it = tap / (p.kh * p.kw); const int rem = tap - it * p.kh * p.kw;
-        iy = rem / p.kw; ix = rem - iy * p.kw;
+        cc = k_begin / ntaps; int rem = k_begin - cc * ntaps;
+        if (p.pm) { iy = iy_lo + rem / p.kw; ix = rem - (iy - iy_lo) * p.kw; }
+        else {
+            it = rem / (p.kh * p.kw); rem -= it * p.kh * p.kw;
+            iy = rem / p.kw; ix = rem - iy * p.kw;
+        }
+        tap = (it * p.kh + iy) * p.kw + ix;
     }
     auto dma = [&](int buf) __attribute__((always_inline)) {
         const int dt_ = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx_ = ix - (p.kw >> 1);
@@ -556,8 +579,14 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) dma16(rw, bbase_ + j * (NWAVE * 1024), (cov[j] && cv_) ? woff[j] + uw_ : 0xffffffffu);
         ++tap;
-        if (++ix == p.kw) { ix = 0; if (++iy == p.kh) { iy = 0; ++it; } }
-        if (tap == ntaps) { tap = 0; it = 0; iy = 0; ix = 0; ++cc; }
+        if (++ix == p.kw) {
+            ix = 0;
+            if (++iy == iy_hi) {                        // (iy_lo, iy_hi) = (0, kh) unless pixel-major
+                iy = iy_lo;
+                if (++it == p.kt) { it = 0; ++cc; }
+                tap = (it * p.kh + iy) * p.kw;
+            }
+        }
     };
 
     f32x16 acc[TM][2];
@@ -611,6 +640,13 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     // 6x slower) and turns the global stores into coalesced 16/32-byte vectors.
     float* ep = reinterpret_cast<float*>(&smem[0][0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
+    if (p.pm) {          // rows of the tile are scattered over the tensor: offsets from its start (small tensors only, see conv_plan)
+        conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, 0ll, [&](int tm, int j) __attribute__((always_inline)) {
+            const int mp = m0 + wm * (TM * 32) + tm * 32 + j * 8 + erow;
+            return mp < p.M ? memrow(mp) : -1;
+        });
+        return;
+    }
     conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (long long)m0, [&](int tm, int j) __attribute__((always_inline)) {
         const int rr = wm * (TM * 32) + tm * 32 + j * 8 + erow;
         return m0 + rr < p.M ? rr : -1;
@@ -1723,6 +1759,17 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;
     const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= big_thr;   // >= 2 workgroups per CU
+    p.pm = 0;
+    {   // pixel-major row order for the tap-by-tap kernel on small frames: the rows of a tile must share their image line
+        static const int use_pm = getenv("DVD_CONV_PIXMAJOR") ? atoi(getenv("DVD_CONV_PIXMAJOR")) : 1;
+        const int bmt = (wide || big) ? 256 : 128;
+        const int F = d->frames;
+        const bool lines = (F % bmt == 0) || (bmt % F == 0 && d->W % (bmt / F) == 0);
+        const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
+        if (use_pm && !halo && pow2 && d->kt == 1 && d->T == 1 && !d->up2 && d->kh >= 3 && d->H <= 8 && lines &&
+            (size_t)M * (size_t)(d->ldi > 3 * d->Cout ? d->ldi : 3 * d->Cout) * 4 < (1ull << 31))     // every epilogue offset from row 0 fits
+            p.pm = F;
+    }
     pl.M = M; pl.halo = halo; pl.thin = thin; pl.wide = wide; pl.big = big;
     return DVD_OK;
 }

@@ -68,6 +68,12 @@ CASES = [
     (3, 72, 200, (16, 16), (3, 3), False, True),     # W = 16: two lines + 2, two in-channel tiles, ReLU
     (2, 24, 72, (16, 64), (3, 3), False, False),     # W = 64: two 32-pixel segments per line, H != W
     (1, 72, 136, (6, 8, 16), (3, 3, 3), False, False),   # 3-D, T = 6
+    # pixel-major row order of the tap-by-tap kernel (frames a multiple / divisor of the tile height, 4 x 4 and 8 x 8 frames):
+    # filter rows outside the frame are skipped per tile
+    (64, 40, 136, (4, 4), (5, 5), False, False),         # 128-row tiles = 2 pixels x 64 frames; ragged N, split-K over fewer steps
+    (128, 16, 24, (8, 8), (3, 3), False, True),          # one pixel per tile
+    (32, 24, 264, (8, 8), (5, 5), False, False),         # 4 pixels x 32 frames, three N tiles
+    (256, 16, 264, (4, 4), (5, 5), False, False),        # 8-wave 256 x 256 tile
     # extents that are not powers of two (latent_dim 3 / 6: 6, 12, 24, 48, 96 pixels): division indexing, tap-by-tap kernels
     (3, 16, 24, (6, 6), (3, 3), False, False),
     (2, 24, 40, (12, 12), (5, 5), False, True),

@@ -324,6 +324,40 @@ def test_convgru_large_rows_uses_fused_gate_epilogue(dtype):
         assert rel(prm.grad, sd[name].grad) < gt, name
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 4, 8, 16, 5), (2, 512, 8, 8, 128, 3), (2, 128, 8, 16, 24, 5)])
+def test_convgru_small_frames_pixel_major_rows(shape):
+    """4 x 4 / 8 x 8 frames with a batch that is a multiple (or divisor) of the tile height: the recurrent convs run the
+    tap-by-tap kernel in PIXEL-major row order and skip the filter rows that fall outside the frame (conv_igemm.hip, ConvK::pm)
+    -- through split-K slabs + gate kernels (few tiles) and through the fused gate epilogues (B = 512: 512 tiles).
+    Exact mode against the CPU oracle, forward and BPTT."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.gen_net import ConvGRUCell
+    T, B, S, cin, hid, k = shape
+    torch.manual_seed(19)
+    cell = ConvGRUCell(cin, hid, k)
+    for p in cell.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.1)
+    sd = O.make_state({kk: v.detach().clone() for kk, v in cell.state_dict().items()}, requires_grad=True)
+    xs = torch.randn(T, B, cin, S, S)
+    gy = torch.randn(T, B, hid, S, S)
+    xr = xs.clone().requires_grad_(True)
+    h, want = None, []
+    for i in range(T):
+        h = O.convgru_cell(sd, "", xr[i], h)
+        want.append(h)
+    want = torch.stack(want)
+    (want * gy).sum().backward()
+    cell = cell.to(DEV)
+    xg = xs.reshape(T * B, cin, S, S).to(DEV).requires_grad_(True)
+    got = ncl(cell.run(cl(xg, torch.float32), T, False), hid).view(T, B, hid, S, S)
+    assert rel(got, want.detach()) < 1e-5
+    (got * gy.to(DEV)).sum().backward()
+    assert rel(xg.grad.view(T, B, cin, S, S), xr.grad) < 2e-5
+    for name, prm in cell.named_parameters():
+        assert rel(prm.grad, sd[name].grad) < 2e-5, name
+
+
 # ------------------------------------------------------------------ BASELINE configs[3] frame size (128 x 128)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_discriminators_at_128x128_frames(dtype):
