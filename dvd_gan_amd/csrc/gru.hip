@@ -244,7 +244,9 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
     // 180.5 / 208.7 -> 171.0 / 196.4 us per step forward / backward); the long loops (C = 512: 400 steps) still do
     const long long target = target_env ? target_env : (ntaps <= 9 || nk < 200 ? 512 : 1024);
     long long ns = (target + tiles - 1) / tiles;
-    static const long long cap = getenv("DVD_NS_CAP") ? atoll(getenv("DVD_NS_CAP")) : 16;
+    // (cap: 8 since the pixel-major tile order skips the out-of-frame filter rows of the 4 x 4 convs -- their K loops are
+    //  shorter, and 16 slabs of 2 MB cost more in the gate kernels than they return: 39.1 / 39.4 -> 34.3 / 34.1 us per step)
+    static const long long cap = getenv("DVD_NS_CAP") ? atoll(getenv("DVD_NS_CAP")) : 8;
     if (ns > cap) ns = cap;
     if (ns > nk) ns = nk;
     if (ns < 1) ns = 1;

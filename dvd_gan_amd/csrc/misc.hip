@@ -55,6 +55,69 @@ __global__ __launch_bounds__(1024) void sn_finish_kernel(int h, int w, float* u,
     if (threadIdx.x == 0) *sigma = n2 / nu;        // u . (W v) = |W v|^2 / (|W v| + eps)
 }
 
+// ---- all matrices of a network at once (dvd_sn_batched).  An item's blocks are found through the block offsets the host
+// stored in the item table; W^T u needs no atomics here: one block owns 256 columns for all rows.
+__device__ __forceinline__ int sn_find_item(const dvd_sn_item* it, int n, int blk, int which) {
+    int lo = 0, hi = n - 1;                      // last item whose first block is <= blk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int first = which == 0 ? it[mid].blk_wtu : which == 1 ? it[mid].blk_wv : it[mid].blk_pack;
+        if (first <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void sn_wtu_batched_kernel(const dvd_sn_item* items, int n) {
+    const int k = sn_find_item(items, n, blockIdx.x, 0);
+    const dvd_sn_item it = items[k];
+    const int j = (blockIdx.x - it.blk_wtu) * 256 + threadIdx.x;
+    if (j >= it.w) return;
+    float a = 0.f;
+    for (int i = 0; i < it.h; ++i) a += it.W[(size_t)i * it.w + j] * it.u[i];
+    it.v[j] = a;
+}
+__global__ __launch_bounds__(256) void sn_wv_batched_kernel(const dvd_sn_item* items, int n, float* t_all) {
+    const int k = sn_find_item(items, n, blockIdx.x, 1);
+    const dvd_sn_item it = items[k];
+    const int i = (blockIdx.x - it.blk_wv) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= it.h) return;
+    float a = 0.f;
+    for (int j = lane; j < it.w; j += 64) a += it.W[(size_t)i * it.w + j] * it.v[j];
+    a = wave_sum(a);
+    if (lane == 0) t_all[(size_t)it.blk_wv * 4 + i] = a;     // (u is still needed by other blocks' W^T u? no: that launch is over)
+}
+__global__ __launch_bounds__(1024) void sn_finish_batched_kernel(const dvd_sn_item* items, const float* t_all, float eps) {
+    __shared__ float sh[32];
+    const dvd_sn_item it = items[blockIdx.x];
+    const float* t = t_all + (size_t)it.blk_wv * 4;
+    float ss = 0.f;
+    for (int j = threadIdx.x; j < it.w; j += blockDim.x) ss += it.v[j] * it.v[j];
+    const float nv = sqrtf(block_sum(ss, sh)) + eps;
+    for (int j = threadIdx.x; j < it.w; j += blockDim.x) it.v[j] = it.v[j] / nv;
+    float s2 = 0.f;
+    for (int i = threadIdx.x; i < it.h; i += blockDim.x) { const float q = t[i] / nv; s2 += q * q; }
+    const float n2 = block_sum(s2, sh);
+    const float nu = sqrtf(n2) + eps;
+    for (int i = threadIdx.x; i < it.h; i += blockDim.x) it.u[i] = (t[i] / nv) / nu;
+    if (threadIdx.x == 0) *it.sigma = n2 / nu;
+}
+template <typename T>
+__device__ __forceinline__ void sn_pack_one(const dvd_sn_item& it, long long i) {
+    const int tap = (int)(i % it.ntaps);
+    const long long r = i / it.ntaps;
+    const int ci = (int)(r % it.cip), co = (int)(r / it.cip);
+    float v = 0.f;
+    if (ci < it.cin) v = it.W[((size_t)co * it.cin + ci) * it.ntaps + tap] / *it.sigma;
+    if (it.wf) stf(reinterpret_cast<T*>(it.wf) + ((size_t)tap * it.cout + co) * it.cip + ci, v);
+    if (it.wd) stf(reinterpret_cast<T*>(it.wd) + ((size_t)(it.ntaps - 1 - tap) * it.cip + ci) * it.cop + co, v);
+}
+__global__ __launch_bounds__(256) void sn_pack_batched_kernel(const dvd_sn_item* items, int n) {
+    const int k = sn_find_item(items, n, blockIdx.x, 2);
+    const dvd_sn_item it = items[k];
+    const long long i = (long long)(blockIdx.x - it.blk_pack) * 256 + threadIdx.x;
+    if (i >= (long long)it.cout * it.cip * it.ntaps) return;
+    if (it.dtype == DVD_BF16) sn_pack_one<bf16_t>(it, i); else sn_pack_one<float>(it, i);
+}
+
 // dot += sum G*W
 __global__ void sn_dot_kernel(const float* G, const float* W, long long n, float* dot) {
     __shared__ float sh[32];
@@ -248,6 +311,35 @@ extern "C" int dvd_sn_power_iter(const float* W, int h, int w, float* u, float* 
     sn_wtu_kernel<<<dim3(cdiv(w, 256), cdiv(h, 64)), 256, 0, S_>>>(W, h, w, u, v);
     sn_wv_kernel<<<cdiv(h, 4), 256, 0, S_>>>(W, h, w, v, u);
     sn_finish_kernel<<<1, 1024, 0, S_>>>(h, w, u, v, sigma, 1e-12f);
+    return launch_status();
+}
+extern "C" int dvd_sn_batched_prepare(dvd_sn_item* host, int n, long long* scratch_floats) {
+    if (!host || n <= 0 || !scratch_floats) return DVD_E_ARG;
+    long long b0 = 0, b1 = 0, b2 = 0;
+    for (int k = 0; k < n; ++k) {
+        dvd_sn_item& it = host[k];
+        if (!it.W || !it.u || !it.v || !it.sigma || it.h <= 0 || it.w <= 0) return DVD_E_ARG;
+        if ((it.wf || it.wd) && (it.cout != it.h || it.cin * it.ntaps != it.w || (it.cip & 7) || it.cip < it.cin ||
+                                 (it.dtype != DVD_BF16 && it.dtype != DVD_F32)))
+            return DVD_E_ARG;
+        it.blk_wtu = (int)b0; it.blk_wv = (int)b1; it.blk_pack = (int)b2;
+        b0 += cdiv(it.w, 256); b1 += cdiv(it.h, 4);
+        b2 += (it.wf || it.wd) ? cdiv((long long)it.cout * it.cip * it.ntaps, 256) : 0;
+        if (b2 >= (1ll << 31)) return DVD_E_SHAPE;
+    }
+    *scratch_floats = b1 * 4;                   // the products W v of all items: 4 floats per block of the second launch
+    return DVD_OK;
+}
+extern "C" int dvd_sn_batched(const dvd_sn_item* host, const dvd_sn_item* dev, int n, float* scratch, void* stream) {
+    if (!host || !dev || !scratch || n <= 0) return DVD_E_ARG;
+    const dvd_sn_item& last = host[n - 1];
+    const unsigned g0 = last.blk_wtu + cdiv(last.w, 256), g1 = last.blk_wv + cdiv(last.h, 4);
+    const unsigned g2 = last.blk_pack + ((last.wf || last.wd) ? cdiv((long long)last.cout * last.cip * last.ntaps, 256) : 0);
+    float* t_all = scratch;
+    sn_wtu_batched_kernel<<<g0, 256, 0, S_>>>(dev, n);
+    sn_wv_batched_kernel<<<g1, 256, 0, S_>>>(dev, n, t_all);
+    sn_finish_batched_kernel<<<n, 1024, 0, S_>>>(dev, t_all, 1e-12f);
+    if (g2) sn_pack_batched_kernel<<<g2, 256, 0, S_>>>(dev, n);
     return launch_status();
 }
 extern "C" int dvd_sn_backward(const float* G, const float* W, const float* u, const float* v, const float* sigma,

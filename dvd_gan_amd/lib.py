@@ -47,7 +47,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def check(code):
@@ -83,3 +83,10 @@ class GruDesc(C.Structure):
                 ("hr_all", C.c_void_p), ("h32", C.c_void_p), ("ws", C.c_void_p),
                 ("dh_out", C.c_void_p), ("dg", C.c_void_p), ("carry", C.c_void_p), ("dh0", C.c_void_p),
                 ("infer", C.c_int)]
+
+
+class SnItem(C.Structure):              # == dvd_sn_item
+    _fields_ = [("W", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
+                ("wf", C.c_void_p), ("wd", C.c_void_p), ("h", C.c_int), ("w", C.c_int),
+                ("dtype", C.c_int), ("cout", C.c_int), ("cin", C.c_int), ("ntaps", C.c_int), ("cip", C.c_int), ("cop", C.c_int),
+                ("blk_wtu", C.c_int), ("blk_wv", C.c_int), ("blk_pack", C.c_int), ("pad_", C.c_int)]

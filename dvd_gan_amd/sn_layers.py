@@ -124,6 +124,34 @@ def prefetch_spectral_norm(net, dtype):
     if side is None:
         side = _SN_STREAMS[dev.index] = torch.cuda.Stream(dev)
     bufs = [m._alloc(dtype, dev) for m in mods]          # allocated (and zero-filled) in main-stream order
+    if os.environ.get("DVD_SN_BATCHED", "1") != "0":
+        # ONE item table, four launches for the whole network (dvd_sn_batched: W^T u, W v, finish, packs) instead of five
+        # launches per layer; every layer waits for the same event
+        import ctypes as C
+        n = len(mods)
+        items = (L.SnItem * n)()
+        for it, m, (sigma, pack) in zip(items, mods, bufs):
+            w = m.module.weight_bar.data
+            it.W, it.u, it.v, it.sigma = w.data_ptr(), m.module.weight_u.data_ptr(), m.module.weight_v.data_ptr(), sigma.data_ptr()
+            it.wf, it.wd = pack.wf.data_ptr(), (pack.wd.data_ptr() if pack.wd is not None else None)
+            it.h, it.w = w.shape[0], w.numel() // w.shape[0]
+            it.dtype, it.cout, it.cin, it.ntaps, it.cip, it.cop = L.dt(pack.wf), pack.cout, pack.cin, pack.ntaps, pack.cip, pack.cop
+        nfl = C.c_longlong()
+        L.check(L.lib().dvd_sn_batched_prepare(items, n, C.byref(nfl)))
+        host = torch.empty(C.sizeof(items), dtype=torch.uint8, pin_memory=True)
+        C.memmove(host.data_ptr(), C.addressof(items), C.sizeof(items))
+        scratch = torch.empty(max(1, nfl.value), dtype=torch.float32, device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            table = host.to(dev, non_blocking=True)
+            L.check(L.lib().dvd_sn_batched(items, C.c_void_p(table.data_ptr()), n, C.c_void_p(scratch.data_ptr()),
+                                           C.c_void_p(side.cuda_stream)))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        scratch.record_stream(side)
+        for m, (sigma, pack) in zip(mods, bufs):
+            m._pre = (sigma, pack, ev)
+        return mods
     side.wait_stream(main)                               # weights, u, v and the fresh buffers are current
     with torch.cuda.stream(side):
         for m, (sigma, pack) in zip(mods, bufs):

@@ -220,6 +220,22 @@ int dvd_sn_power_iter(const float* W, int h, int w, float* u, float* v, float* s
 int dvd_sn_backward(const float* G, const float* W, const float* u, const float* v, const float* sigma, int h, int w,
                     float* dW, float* scratch /*1 float*/, void* stream);
 int dvd_sn_scale(const float* W, const float* sigma, float* out, long long n, void* stream);
+/* The power iterations AND the sigma-normalised MFMA weight images of ALL spectrally normalised convolutions of a network in
+ * four launches (the reference runs Normalization.py:19-31 inside every layer's forward): W^T u for every matrix,
+ * W v, the finish step (norms, u, v, sigma), the two packs of dvd_pack_conv_weight (whole weight, co_off 0).  `host`: the n
+ * items; `dev`: the same array in device memory (the caller uploads it AFTER dvd_sn_batched_prepare has filled the block
+ * offsets and reported the scratch size).  wf / wd may be NULL (power iteration only). */
+typedef struct {
+    const float* W; float* u; float* v; float* sigma;      /* [h][w] fp32, [h], [w], [1]                                    */
+    void* wf; void* wd;                                    /* packs [ntaps][cout][cip], [ntaps][cip][cop] in `dtype`, or NULL */
+    int h, w;                                              /* matrix view: h = cout, w = cin * ntaps                         */
+    int dtype, cout, cin, ntaps, cip, cop;
+    int blk_wtu, blk_wv, blk_pack;                         /* first block of this item in the three batched launches (prepare) */
+    int pad_;
+} dvd_sn_item;
+int dvd_sn_batched_prepare(dvd_sn_item* host, int n, long long* scratch_floats);
+int dvd_sn_batched(const dvd_sn_item* host, const dvd_sn_item* dev, int n, float* scratch /* *scratch_floats floats */,
+                   void* stream);
 
 /* fp32 nn.Linear (Generator.py:75, Normalization.py:80) and nn.Embedding backward (Generator.py:70) */
 int dvd_linear_forward(const float* in, const float* W, const float* bias, float* out, int B, int K, int J, void* stream);

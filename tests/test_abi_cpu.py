@@ -36,7 +36,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.dvd_conv_forward(ctypes.byref(d), None) == -1
     w = L.WgradDesc()
     assert lib.dvd_conv_wgrad(ctypes.byref(w), None) == -1
-    assert lib.dvd_conv_pick_nsplit(L.BF16, ctypes.c_longlong(1024), 512, 512, 25) == 16
+    assert lib.dvd_conv_pick_nsplit(L.BF16, ctypes.c_longlong(1024), 512, 512, 25) == 8       # capped
     assert lib.dvd_conv_pick_nsplit(L.BF16, ctypes.c_longlong(65536), 512, 256, 25) == 1
     with pytest.raises(RuntimeError):
         L.check(-2)
