@@ -36,13 +36,14 @@ def is_trainable(key):
     return not key.endswith(_NO_GRAD_SUFFIX)
 
 
-def make_state(arrays, requires_grad=True):
-    """dict of numpy / tensors (reference state_dict keys) -> dict of fp32 leaf tensors."""
+def make_state(arrays, requires_grad=True, dtype=torch.float32):
+    """dict of numpy / tensors (reference state_dict keys) -> dict of leaf tensors (fp32; fp64 to measure what fp32 rounding
+    alone does to a fixture)."""
     sd = {}
     for k, v in arrays.items():
         t = torch.as_tensor(v).clone()
         if t.is_floating_point():
-            t = t.float()
+            t = t.to(dtype)
             if requires_grad and is_trainable(k):
                 t.requires_grad_(True)
         sd[k] = t
