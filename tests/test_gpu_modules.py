@@ -578,38 +578,34 @@ def test_generator_with_latent_dim_that_is_not_a_power_of_two(ld, dtype):
     torch.manual_seed(23)
     ch, T, B, ncls, zd = 2, 4, 3, 3, 12
     G = Generator(zd, ld, ncls, ch, T, compute_dtype=dtype)
+    # the ConvGRU weights of the default initialisation come out of LAPACK (orthogonal_) and differ from machine to machine:
+    # replace them by the closed-form uniform weights of tests/golden/synth.py, so that every box tests the same fixture
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import synth
+    with torch.no_grad():
+        for kk, prm in G.named_parameters():
+            if ".cells." in kk and prm.dim() == 4:
+                prm.copy_(torch.from_numpy(synth.weight("ld%d.%s" % (ld, kk), tuple(prm.shape))))
     sd = O.make_state({k: v.detach().clone() for k, v in G.state_dict().items()})
     z, cls = torch.randn(B, zd), torch.randint(0, ncls, (B,))
     want = O.generator(sd, z, cls, ch, T, latent_dim=ld)
     assert want.shape == (B, T, 3, 16 * ld, 16 * ld)
     gy = torch.randn_like(want)
     want.backward(gy)
-    # Conditioning of this ch=2 end-to-end fixture (see GEN_TOL): the oracle in fp64, and again with every weight moved by
-    # ONE fp32 ulp (2^-24, random sign) -- the least any fp32 implementation perturbs them.  At latent_dim 6 that alone moves
-    # the early layers' gradients by 5e-3 ... 1e-2 (the clips by 1e-6).
-    sd64 = O.make_state({k: v.detach().clone() for k, v in G.state_dict().items()}, dtype=torch.float64)
-    O.generator(sd64, z.double(), cls, ch, T, latent_dim=ld).backward(gy.double())
-    sdp = O.make_state({k: v.detach().clone() for k, v in G.state_dict().items()}, dtype=torch.float64)
-    gen = torch.Generator().manual_seed(1)
-    with torch.no_grad():
-        for v in sdp.values():
-            if v.requires_grad:
-                v.mul_(1 + (torch.randint(0, 2, v.shape, generator=gen).double() * 2 - 1) * 2.0 ** -24)
-    O.generator(sdp, z.double(), cls, ch, T, latent_dim=ld).backward(gy.double())
     G = G.to(DEV).train()
     got = G(z.to(DEV), cls.to(DEV))
     assert got.shape == want.shape
     if dtype == torch.bfloat16:
-        # default (orthogonal) initialisation: the free-running bf16 generator sits at the one-ulp sensitivity of the
-        # recurrence (tests/test_gpu_fullwidth.py, test_sensitivity_of_the_free_running_generator) -- this case only shows that
-        # the bf16 kernels serve these extents; the exact-mode cases carry the parity statement
-        assert torch.isfinite(got).all() and rel(got, want.detach()) < 0.35
+        # this case shows that the bf16 kernels serve these extents; the exact-mode cases carry the parity statement
+        assert torch.isfinite(got).all() and rel(got, want.detach()) < 0.1
         return
     assert rel(got, want.detach()) < 2e-4
     got.backward(gy.to(DEV))
     for name in ("conv.0.cells.0.update_gate.weight", "conv.3.cells.1.out_gate.weight", "conv.9.cells.2.reset_gate.weight",
                  "conv.4.conv0.module.weight_bar", "conv.11.conv_sc.module.weight_bar", "conv.7.CBNorm1.embed.weight",
                  "colorize.module.weight_bar", "affine_transfrom.weight"):
-        # judged against the fp64 oracle: within 3x the one-ulp sensitivity (+ 1e-4)
-        cond = rel(sdp[name].grad, sd64[name].grad)
-        assert rel(dict(G.named_parameters())[name].grad, sd64[name].grad) < 3 * cond + 1e-4, (name, cond)
+        # ch=2 end-to-end fixture: fp32 rounding is amplified on the way back through four recurrences (see GEN_TOL: 1e-2 for
+        # the 64 x 64 fixtures)
+        assert rel(dict(G.named_parameters())[name].grad, sd[name].grad) < 1e-2, name
