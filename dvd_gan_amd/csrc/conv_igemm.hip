@@ -1670,7 +1670,7 @@ extern "C" long long dvd_prof_report_variants(int kind, int nvar, long long* n, 
         if (r.kind != kind) { keep.push_back(r); continue; }
         hipEventSynchronize(r.b);
         float t = 0; hipEventElapsedTime(&t, r.a, r.b);
-        if (f) fprintf(f, "%d,%lld,%d,%d,%d,%d,%d,%.4f,%.0f\n", r.kind, r.M, r.C, r.Cout, r.taps, r.split, r.flags, t, r.flops);
+        if (f) fprintf(f, "%d,%lld,%d,%d,%d,%d,%d,%.4f,%.0f,%d\n", r.kind, r.M, r.C, r.Cout, r.taps, r.split, r.flags, t, r.flops, r.variant);
         const int slots[2] = {0, r.variant};                    // slot 0 = all launches, plus the record's own slot
         for (int j = 0; j < (r.variant > 0 ? 2 : 1); ++j) {
             const int v = slots[j];

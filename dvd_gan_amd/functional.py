@@ -29,7 +29,9 @@ from . import lib as L
 # zero_grad(set_to_none=True), module tests) take the autograd route unchanged.
 import os as _os
 _SIDE = {"on": False, "stream": None, "serial": _os.environ.get("DVD_SIDE_SERIAL") == "1",      # env: profiling aid, see below
-         "cb": False}                                                                           # join callback queued for the running backward
+         "cb": False,                                                                           # join callback queued for the running backward
+         "defer": False, "queue": [],                                                           # held-back weight-gradient launches
+         "defer_hw": int(_os.environ.get("DVD_DEFER_HW", "16"))}                                # frame extent from which the time loops release them
 
 
 def direct_weight_grads(flag):
@@ -44,8 +46,36 @@ def serialize_weight_grads(flag):
     _SIDE["serial"] = bool(flag)
 
 
+def _cu_mask(n_cus, pattern, total=256):
+    """Mask words selecting n_cus of `total` compute units.  pattern 0: CUs [0, n); 1: evenly spread (every total/n-th);
+    2: half of the chip such that every XCD keeps half of its CUs whether mask bits run XCD-interleaved or XCD by XCD."""
+    words = [0] * ((total + 31) // 32)
+    for i in range(total):
+        if pattern == 0:
+            on = i < n_cus
+        elif pattern == 1:
+            on = (i * n_cus) // total != ((i + 1) * n_cus) // total
+        else:
+            on = ((i >> 3) ^ i ^ (i >> 5)) & 1 == 1
+        if on:
+            words[i // 32] |= 1 << (i % 32)
+    return words
+
+
 def side_stream():
     if _SIDE["stream"] is None:
+        n_cus = int(_os.environ.get("DVD_SIDE_CUS", "0"))
+        if n_cus > 0:         # experiment: the weight-gradient stream on a subset of the CUs (see DESIGN.md section 4, round 3)
+            import ctypes as C
+            from .lib import lib
+            words = _cu_mask(n_cus, int(_os.environ.get("DVD_SIDE_CUPAT", "0")))
+            arr = (C.c_uint * len(words))(*words)
+            out = C.c_void_p()
+            rc = lib().dvd_stream_create_cumask(arr, len(words), C.byref(out))
+            if rc != 0:
+                raise RuntimeError("dvd_stream_create_cumask failed (%d)" % rc)
+            _SIDE["stream"] = torch.cuda.ExternalStream(out.value)
+            return _SIDE["stream"]
         lo, hi = 0, 0
         try:
             lo, hi = torch.cuda.Stream.priority_range()          # (least, greatest) priority; smaller = more urgent
@@ -55,8 +85,41 @@ def side_stream():
     return _SIDE["stream"]
 
 
+def defer_weight_grads(flag):
+    """While on, the side-stream weight-gradient launches of a backward pass are HELD BACK (in launch order) until the pass
+    reaches a ConvGRU layer whose frames are DVD_DEFER_HW (16) pixels wide or less -- or until the join.  Those time loops are
+    chains of launches too small to fill the chip; beside the large convolutions that come first in a backward pass the weight
+    gradients only time-share the CUs.  OFF unless DVD_SIDE_DEFER=1: measured 537.9-543.0 ms per step against 535.9-536.0 without
+    (round 3, tools/ab_defer.sh) -- the released kernels take every CU and the time loop waits for them."""
+    _SIDE["defer"] = bool(flag) and _os.environ.get("DVD_SIDE_DEFER", "0") == "1"
+    if not _SIDE["defer"]:
+        flush_deferred()
+
+
+def flush_deferred():
+    """Launch the held-back weight-gradient work now (on the side stream, ordered after the current stream's queue)."""
+    q = _SIDE["queue"]
+    if not q:
+        return
+    _SIDE["queue"] = []
+    with _on_side(*[t for _, ts in q for t in ts]):
+        for fn, _ in q:
+            fn()
+
+
+def _side_run(fn, *tensors):
+    """fn() launches weight-gradient kernels: on the side stream now, or later (see defer_weight_grads)."""
+    if _SIDE["defer"] and not _SIDE["serial"]:
+        _queue_join()
+        _SIDE["queue"].append((fn, [t for t in tensors if t is not None]))
+        return
+    with _on_side(*tensors):
+        fn()
+
+
 def join_side():
     """The current stream waits for everything queued on the weight-gradient stream."""
+    flush_deferred()
     if _SIDE["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
 
@@ -213,15 +276,18 @@ class Conv(Function):
         wp, bp = ctx.params
         if ctx.needs_input_grad[1] and _direct(wp, bp if ctx.needs_input_grad[2] else None):
             # side stream, straight into the persistent .grad buffers (see the note at the top of this file)
-            with _on_side(x, dy, w, ctx.sigma):
-                dbp = bp.grad if (ctx.needs_input_grad[2] and bp is not None) else None
+            dbp = bp.grad if (ctx.needs_input_grad[2] and bp is not None) else None
+            sigma = ctx.sigma
+
+            def wgrad():
                 if spec.sn is not None:
                     G = torch.zeros_like(w)
                     K.conv_wgrad(x, dy, G, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp)
                     u, v = spec.sn        # CURRENT u / v on purpose (reference quirk 7): no forward runs before the join
-                    K.sn_backward(G, w, u, v, ctx.sigma, out=wp.grad)
+                    K.sn_backward(G, w, u, v, sigma, out=wp.grad)
                 else:
                     K.conv_wgrad(x, dy, wp.grad, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp)
+            _side_run(wgrad, x, dy, w, sigma)
         elif ctx.needs_input_grad[1]:
             G = torch.zeros_like(w)
             if ctx.needs_input_grad[2]:           # bias gradient rides along in the wgrad kernel
@@ -370,6 +436,8 @@ class ConvGRULayer(Function):
         T, B, S1, S2, hid, cin, k, shared_x, ws_n = ctx.meta
         dev, dtype = x.device, x.dtype
         M = B * S1 * S2
+        if max(S1, S2) <= _SIDE["defer_hw"]:
+            flush_deferred()          # this time loop leaves CUs idle: the held-back weight gradients run beside it
         dh = dh.contiguous()
         dg = torch.empty(T * B, S1, S2, 3 * hid, dtype=dtype, device=dev)
         carry = torch.empty(M, hid, dtype=torch.float32, device=dev)
@@ -415,8 +483,7 @@ class ConvGRULayer(Function):
                                      frames=(T - 1) * B, x_row0=B, dy_row0=B)
 
         if direct:
-            with _on_side(x, dgx, dg, h_all, hr_all, h0):
-                gate_wgrads([p.grad for p in wparams], [p.grad for p in bparams])
+            _side_run(lambda: gate_wgrads([p.grad for p in wparams], [p.grad for p in bparams]), x, dgx, dg, h_all, hr_all, h0)
             grads, dbl = [None, None, None], [None, None, None]
         else:
             db3 = torch.zeros(3 * hid, dtype=torch.float32, device=dev)

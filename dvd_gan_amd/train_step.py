@@ -299,8 +299,12 @@ class Trainer(object):
                 ex.start_range("G", self.g_optimizer.grad, lo, self._g_hi)
                 self._g_hi = min(self._g_hi, lo)
             self.G.grad_ready_hook = on_ready
+        # experiment switch (DVD_SIDE_DEFER=1, single GPU): G's weight gradients held back until the backward pass reaches the
+        # small-frame ConvGRU time loops (functional.defer_weight_grads; measured: no gain)
+        Fn.defer_weight_grads(ex.world == 1)
         (g_s_loss + g_t_loss).backward()
         Fn.join_side()
+        Fn.defer_weight_grads(False)
         if ex.world > 1:
             self.G.grad_ready_hook = None
             ex.start_range("G", self.g_optimizer.grad, 0, self._g_hi)

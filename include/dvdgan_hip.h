@@ -46,6 +46,11 @@ long long dvd_prof_report(int kind, double* total_ms, double* total_flops);
  * 5 = conv_igemm 256x128, 6 = conv_igemm 256x256; kind 1: 1 = filter-row kernel, 2 = one-tap kernel. */
 long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops);
 const char* dvd_strerror(int code);
+/* A HIP stream restricted to a set of compute units (bit i of the nwords 32-bit mask words = CU i), for work that should
+ * fill the chip beside a latency-bound chain of small launches without taking every CU from it (the weight-gradient stream of
+ * dvd_gan_amd/functional.py); *stream receives a hipStream_t.  dvd_stream_destroy releases it. */
+int dvd_stream_create_cumask(const unsigned* mask, int nwords, void** stream);
+int dvd_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, stride 1, "same" zero padding, 1-D/2-D/3-D taps (kt,kh,kw odd).

@@ -74,8 +74,11 @@ def test_reference_loop_with_stock_adam(golden):
         np.testing.assert_allclose(psum[big], ref[big], rtol=1e-3 if s == 0 else 2e-2)
 
 
-def test_persistent_grads_are_joined_when_backward_returns(golden):
-    """once a Trainer has switched the direct weight-gradient route on, ANY backward() over parameters whose .grad
+@pytest.mark.parametrize("held_back", [False, True])
+def test_persistent_grads_are_joined_when_backward_returns(golden, held_back, monkeypatch):
+    """held_back: the same with the weight-gradient launches held back until the small-frame time loops / the join
+    (functional.defer_weight_grads, an opt-in experiment switch) and the side stream restricted to 192 CUs.
+    ADVICE r2: once a Trainer has switched the direct weight-gradient route on, ANY backward() over parameters whose .grad
     is a persistent fp32 buffer (stock optimizer + zero_grad(set_to_none=False), gradient accumulation, a tool driving
     the generator alone) accumulates on the side stream.  The join is queued as a final callback of the autograd engine:
     when backward() returns the calling stream already waits for it, so reading / stepping right away is race-free.
@@ -94,6 +97,12 @@ def test_persistent_grads_are_joined_when_backward_returns(golden):
     def two_backwards(direct):
         G.load_state_dict(sd0)                                  # same SN u / v, BN statistics for both routes
         Fn.direct_weight_grads(direct)
+        if held_back and direct:
+            monkeypatch.setenv("DVD_SIDE_DEFER", "1")
+            monkeypatch.setenv("DVD_SIDE_CUS", "192")
+            Fn._SIDE["stream"] = None                           # built again, from dvd_stream_create_cumask
+            Fn.defer_weight_grads(True)
+            assert Fn._SIDE["defer"]
         for p in G.parameters():
             p.grad = torch.zeros_like(p) if (direct and p.requires_grad) else None    # persistent buffers <-> set-to-none
         for _ in range(2):                                      # second pass accumulates
@@ -104,8 +113,14 @@ def test_persistent_grads_are_joined_when_backward_returns(golden):
         ref = two_backwards(False)
         got = two_backwards(True)
         assert Fn._SIDE["stream"] is not None                   # the side stream really was used
+        assert not Fn._SIDE["queue"]                            # nothing left behind
+        if held_back:
+            assert isinstance(Fn._SIDE["stream"], torch.cuda.ExternalStream)
     finally:
+        Fn.defer_weight_grads(False)
         Fn.direct_weight_grads(False)
+        if held_back:
+            Fn._SIDE["stream"] = None
     assert set(got) == set(ref)
     scale = max(float(v.norm()) for v in ref.values())
     for kk in ref:
