@@ -717,6 +717,11 @@ class VidDownsample(Function):
         return K.vid_downsample_raw(g.contiguous(), True, ctx.shape)
 
 
+def _ids_to(ids, device):
+    from .helpers import to_device_async
+    return to_device_async(ids, device)
+
+
 class GatherFrames(Function):
     """data[:, ids] for [B, T, ...] fp32 data (utils.py:63)"""
 
@@ -724,7 +729,7 @@ class GatherFrames(Function):
     def forward(ctx, x, ids):
         B, T = x.shape[:2]
         k = ids.numel()
-        rows = (torch.arange(B, device=x.device).view(B, 1) * T + ids.view(1, k).to(x.device)).reshape(-1).int()
+        rows = (torch.arange(B, device=x.device).view(B, 1) * T + _ids_to(ids.view(1, k), x.device)).reshape(-1).int()
         Lr = x[0, 0].numel()
         ctx.save_for_backward(rows)
         ctx.shape = tuple(x.shape)

@@ -4,6 +4,20 @@ import torch
 from . import functional as Fn
 
 
+def to_device_async(t, device):
+    """Host tensor -> device without stalling the host: through a pinned staging block, non_blocking.  A plain `.to(device)`
+    of pageable memory makes the host wait for everything queued on the current stream -- once per step that keeps the host
+    from running ahead of the GPU, and every launch gap of the step's Python becomes GPU idle time.  (The pinned block comes
+    from torch's caching host allocator, which reuses it only after the copy has executed.)"""
+    if t.is_cuda or not torch.cuda.is_available():
+        return t.to(device)
+    if not t.is_pinned():
+        if t.numel() * t.element_size() > (1 << 20):
+            return t.to(device)           # a batch of clips: pin it in the loader (make_loader does); no extra host copy here
+        t = t.pin_memory()
+    return t.to(device, non_blocking=True)
+
+
 def draw_frame_ids(video_length, k_sample, generator=None):
     """`torch.randperm(T)[:k].sort()` on the CPU default generator, like the reference."""
     perm = torch.randperm(video_length, generator=generator)

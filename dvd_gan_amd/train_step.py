@@ -20,7 +20,7 @@ from . import dist as D
 from .dist import GradExchange
 from .disc_nets import SpatialDiscriminator, TemporalDiscriminator
 from .gen_net import Generator
-from .helpers import denorm, draw_frame_ids, sample_k_frames, vid_downsample
+from .helpers import denorm, draw_frame_ids, sample_k_frames, to_device_async, vid_downsample
 from .optim import FlatAdam
 
 
@@ -184,7 +184,7 @@ class Trainer(object):
 
     # ---- trainer.py:84-88
     def label_sample(self):
-        return torch.randint(low=0, high=self.n_class, size=(self.batch_size,), generator=self.noise_gen).to(self.device)
+        return to_device_async(torch.randint(low=0, high=self.n_class, size=(self.batch_size,), generator=self.noise_gen), self.device)
 
     # ---- trainer.py:384-387
     def reset_grad(self):
@@ -238,8 +238,8 @@ class Trainer(object):
         return out
 
     def _train_step(self, real_videos, real_labels, draws=None, hidden=None):
-        real_videos = real_videos.to(self.device).permute(0, 2, 1, 3, 4).contiguous()
-        real_labels = self._check_labels(real_labels).to(self.device)
+        real_videos = to_device_async(real_videos, self.device).permute(0, 2, 1, 3, 4).contiguous()
+        real_labels = to_device_async(self._check_labels(real_labels), self.device)
         T, k = self.n_frames, self.k_sample
         ex = self.exchange
         fg = self.frame_gen
@@ -249,9 +249,9 @@ class Trainer(object):
                 draws = draws_all[_]
             ids_real = draw_frame_ids(T, k, fg) if draws is None else torch.as_tensor(draws["perm_real"])[:k].sort()[0]
             real_s = sample_k_frames(real_videos, T, k, ids_real)
-            z = (torch.randn(self.batch_size, self.z_dim, generator=self.noise_gen) if draws is None
-                 else torch.as_tensor(draws["z"])).to(self.device)
-            z_class = self.label_sample() if draws is None else self._check_labels(torch.as_tensor(draws["z_class"])).to(self.device)
+            z = to_device_async(torch.randn(self.batch_size, self.z_dim, generator=self.noise_gen) if draws is None
+                                else torch.as_tensor(draws["z"]), self.device)
+            z_class = self.label_sample() if draws is None else to_device_async(self._check_labels(torch.as_tensor(draws["z_class"])), self.device)
             ex.finish("G")
             fake_videos = self.G(z, z_class, hidden)
             ids_fake = draw_frame_ids(T, k, fg) if draws is None else torch.as_tensor(draws["perm_fake"])[:k].sort()[0]
