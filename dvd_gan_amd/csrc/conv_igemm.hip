@@ -895,12 +895,15 @@ __device__ __forceinline__ void conv_halo_tile(const ConvK& p, char* const smem,
                     }
                 }
             }
+#ifndef DVD_EXP_NODMA          // DVD_EXP_*: compile-time measurement variants (tools/build_variant.sh), results are garbage
             if (late) {
                 if (issueB) dmaB(st2);
                 if (issueH) { dmaH(hb ^ 1, h_cc, h_it); if (++h_it == p.kt) { h_it = 0; ++h_cc; } }
             }
+#endif
             // In-order completion: weight tile sidx+1 has landed once at most the FL younger tiles (plus, for the
             // NSTAGE-1 steps after a footprint went out behind tile sidx+NSTAGE-1, that footprint) are outstanding.
+#ifndef DVD_EXP_NOWAIT
             {
                 const int younger = min(FL, nsteps - 2 - sidx);          // tiles issued beyond sidx+1
                 const bool hpend = m_tap < NSTAGE - 1 && m_oc + 1 < oc_end;
@@ -913,7 +916,10 @@ __device__ __forceinline__ void conv_halo_tile(const ConvK& p, char* const smem,
                     __builtin_amdgcn_s_waitcnt(VMCNT(0));
                 }
             }
+#endif
+#ifndef DVD_EXP_NOBAR
             __builtin_amdgcn_s_barrier();
+#endif
             st = st == NSTAGE - 1 ? 0 : st + 1;
             st2 = st2 == NSTAGE - 1 ? 0 : st2 + 1;
             ++m_tap;
