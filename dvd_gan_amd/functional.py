@@ -358,16 +358,16 @@ class CondBatchNorm(Function):
         cross-replica batch norm (Generator.py:57 TODO): statistics and their backward sums span the global batch."""
         mean, rstd = K.bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas if training else None)
         y = K.cbn_apply(x, C_real, mean, rstd, gb, samp, relu)
-        ctx.save_for_backward(x, y, gb, samp, mean, rstd)
+        ctx.save_for_backward(x, gb, samp, mean, rstd)      # (not y: the backward re-evaluates the ReLU mask from x)
         ctx.C_real, ctx.relu, ctx.training, ctx.replicas = C_real, relu, training, replicas
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, gb, samp, mean, rstd = ctx.saved_tensors
+        x, gb, samp, mean, rstd = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError("CondBatchNorm backward is implemented for training mode only")
-        dx, dgb = K.cbn_backward(g.contiguous(), y, x, ctx.C_real, mean, rstd, gb, samp, ctx.relu, ctx.replicas)
+        dx, dgb = K.cbn_backward(g.contiguous(), None, x, ctx.C_real, mean, rstd, gb, samp, ctx.relu, ctx.replicas)
         return dx, dgb, None, None, None, None, None, None, None, None, None
 
 

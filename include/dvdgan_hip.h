@@ -187,8 +187,9 @@ int dvd_bn_finalize(const double* sums, long long rows, int C, float eps, float 
                     float* mean, float* rstd, float* run_mean, float* run_var, void* stream);
 int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames, int P, int C, int ld, const float* mean,
                   const float* rstd, const float* gb, const int* samp, int relu, void* stream);
-/* g: gradient wrt the (ReLU'd) output, a: that output (ReLU mask), x: CBN input.  Produces dx and
- * accumulates dgb[B][2C] (zeroed by the caller); s12[2C] is scratch. */
+/* g: gradient wrt the (ReLU'd) output, x: CBN input.  Produces dx and accumulates dgb[B][2C] (zeroed by the caller);
+ * s12[2C] is scratch.  a (the stored output) is NOT read and may be NULL: with relu the mask is re-evaluated from x by the
+ * same fused multiply-add the forward used (two HBM passes fewer than reading it). */
 int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames, int P,
                      int C, int ld, const float* mean, const float* rstd, const float* gb, const int* samp, int B,
                      float* dgb, float* s12, int relu, void* stream);

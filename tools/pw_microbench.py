@@ -41,7 +41,7 @@ def main():
         print(f"cbn_apply    {F_}x{H}x{W}x{C}: {ms * 1e3:8.1f} us  {2 * nbytes / ms / 1e6:7.0f} GB/s (2 passes)", flush=True)
         a = K.cbn_apply(x, C, mean, rstd, gb, samp, True)
         ms = bench(lambda: K.cbn_backward(g, a, x, C, mean, rstd, gb, samp, True), iters)
-        print(f"cbn_backward {F_}x{H}x{W}x{C}: {ms * 1e3:8.1f} us  {7 * nbytes / ms / 1e6:7.0f} GB/s (3+4 passes)", flush=True)
+        print(f"cbn_backward {F_}x{H}x{W}x{C}: {ms * 1e3:8.1f} us  {5 * nbytes / ms / 1e6:7.0f} GB/s (2+3 passes)", flush=True)
 
 
 if __name__ == "__main__":
