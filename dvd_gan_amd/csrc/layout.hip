@@ -133,7 +133,7 @@ extern "C" int dvd_stream_destroy(void* stream) {
     return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? DVD_OK : DVD_E_LAUNCH;
 }
 
-extern "C" int dvd_abi_version(void) { return 7; }
+extern "C" int dvd_abi_version(void) { return 8; }
 extern "C" const char* dvd_strerror(int code) {
     switch (code) {
         case DVD_OK: return "ok";

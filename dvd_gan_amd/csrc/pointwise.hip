@@ -3,11 +3,14 @@
 // helpers.  All of them move 16-byte (bf16) / 32-byte (f32) channel groups per thread and are
 // bounded by HBM bandwidth; statistics accumulate in fp64.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 // ----------------------------------------------------------------------------- BN statistics
-// sums[0..C) += sum_rows x, sums[C..2C) += sum_rows x^2          (fp64 atomics, caller zeroes)
+// sums[rep][0..C) += sum_rows x, sums[rep][C..2C) += sum_rows x^2, rep = block % DVD_BN_NREP   (fp64 atomics, caller zeroes).
+// The atomics of all blocks on ONE copy serialise at ~0.17 us each per address (512 blocks: 87 us of a 126 us launch on
+// 3072 x 8 x 8 x 512); DVD_BN_NREP copies, added up by bn_finalize_kernel, divide that tail by DVD_BN_NREP.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long long rows, int C, int ld, double* sums) {
     __shared__ double red[256][17];
@@ -46,7 +49,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = g * 8 + i;
-            if (c < C) { atomicAdd(sums + c, s[i]); atomicAdd(sums + C + c, q[i]); }
+            double* dst = sums + (size_t)(blockIdx.x % DVD_BN_NREP) * 2 * C;
+            if (c < C) { atomicAdd(dst + c, s[i]); atomicAdd(dst + C + c, q[i]); }
         }
     }
 }
@@ -57,8 +61,10 @@ __global__ void bn_finalize_kernel(const double* sums, double n, int C, float ep
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (training) {
-        const double m = sums[c] / n;
-        double var = sums[C + c] / n - m * m;
+        double s1 = 0, s2 = 0;
+        for (int r = 0; r < DVD_BN_NREP; ++r) { s1 += sums[(size_t)r * 2 * C + c]; s2 += sums[(size_t)r * 2 * C + C + c]; }
+        const double m = s1 / n;
+        double var = s2 / n - m * m;
         if (var < 0) var = 0;
         mean[c] = (float)m;
         rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -477,7 +483,12 @@ extern "C" int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int
     if ((ld & 7) || C > ld || (C + 7) / 8 > 256) return DVD_E_SHAPE;
     const int nj = 256 / ((C + 7) / 8);
     unsigned grid = cdiv(rows, (long long)nj * 16);
-    if (grid > 512) grid = 512;             // every block ends with 2C fp64 atomics on the same addresses (U = 8 / 1024 blocks measured slower)
+    // every block ends with 2C fp64 atomics: 1024 blocks while that stays <= 256 k atomics per launch (3072 x 64 x 64 x 64: 459 us with
+    // 512 blocks on one copy of the sums, 418 on 16 copies, 296 with 1024 blocks = 5.4 TB/s), 512 blocks for wider tensors
+    // (C = 256 / 512: 112 / 63 us against 123 / 80 with 1024); 64 copies of the sums: no further gain
+    static const unsigned forced = getenv("DVD_BN_GRID") ? (unsigned)atoi(getenv("DVD_BN_GRID")) : 0u;
+    const unsigned cap = forced ? forced : (C <= 128 ? 1024u : 512u);
+    if (grid > cap) grid = cap;
     BY_DTYPE(dtype, bn_stats_kernel<T><<<grid, 256, 0, S_>>>((const T*)x, rows, C, ld, sums));
     return launch_status();
 }

@@ -180,7 +180,7 @@ def _f(v):
 
 def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas=None):
     """-> (mean, rstd) fp32 [C_real]; updates the running buffers in training mode.
-    replicas: None, or (world, all_reduce_sum_) for cross-replica statistics -- the [2C] fp64 sums are added over the
+    replicas: None, or (world, all_reduce_sum_) for cross-replica statistics -- the [BN_NREP][2C] fp64 sums are added over the
     replicas before mean / variance are formed from world * rows samples."""
     ld = x.shape[-1]
     rows = x.numel() // ld
@@ -188,7 +188,7 @@ def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas=Non
     rstd = torch.empty_like(mean)
     sums = None
     if training:
-        sums = torch.zeros(2 * C_real, dtype=torch.float64, device=x.device)
+        sums = torch.zeros(L.BN_NREP * 2 * C_real, dtype=torch.float64, device=x.device)
         L.check(L.lib().dvd_bn_stats(L.dt(x), L.ptr(x), _ll(rows), C_real, ld, L.ptr(sums), L.stream()))
         if replicas is not None:
             replicas[1](sums)

@@ -47,7 +47,8 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
+BN_NREP = 16            # DVD_BN_NREP of include/dvdgan_hip.h
 
 
 def check(code):

@@ -182,7 +182,8 @@ int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps);
  * is where the reference's condition mis-ordering, Generator.py:109-110, is expressed).
  * gb = Linear(cond) as [B][2*C] (gamma | beta), computed with dvd_linear_forward.
  * ---------------------------------------------------------------------------------------- */
-int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int ld, double* sums /*[2C], zeroed*/, void* stream);
+#define DVD_BN_NREP 16      /* copies of the [2C] sums the statistics kernel spreads its atomics over (dvd_bn_finalize adds them up) */
+int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int ld, double* sums /*[DVD_BN_NREP][2C], zeroed*/, void* stream);
 int dvd_bn_finalize(const double* sums, long long rows, int C, float eps, float momentum, int training,
                     float* mean, float* rstd, float* run_mean, float* run_var, void* stream);
 int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames, int P, int C, int ld, const float* mean,
