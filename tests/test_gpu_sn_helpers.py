@@ -74,3 +74,47 @@ def test_f8_helpers(golden):
     mask = torch.zeros(6)
     mask[torch.as_tensor(ids4)] = 1
     assert torch.equal(xs.grad.cpu(), mask.view(1, 6, 1, 1, 1).expand_as(xs.grad.cpu()).contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cbn_backward_relu_mask_from_x_equals_the_stored_activation(dtype):
+    """The CBN backward kernels do not read the stored activation: they re-evaluate gamma * xhat + beta from x (the same fused
+    multiply-add as the forward, `cbn_affine`) and mask with its sign.  Checked where it could go wrong: beta is chosen so that
+    the pre-activation of MANY elements sits within a few ulps of zero, and the result is compared with a torch evaluation that
+    masks with the activation the forward kernel actually stored.  A single element masked differently would show up as a
+    gradient error of the size of that element's incoming gradient (O(1))."""
+    from dvd_gan_amd import kern as K
+    torch.manual_seed(3)
+    F_, H, W, C, B = 24, 8, 8, 16, 4
+    x = torch.randn(F_, H, W, C, device=DEV).to(dtype)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, rstd = K.bn_stats(x, C, True, 1e-5, 0.1, rm, rv)
+    # statistics through the 16 copies of the sums: against torch in fp64
+    xd = x.double().reshape(-1, C)
+    assert rel(mean, xd.mean(0).cpu()) < 1e-6 and rel(rstd, (1.0 / (xd.var(0, unbiased=False) + 1e-5).sqrt()).cpu()) < 1e-6
+    samp = (torch.arange(F_, device=DEV, dtype=torch.int32) % B).contiguous()
+    gamma = torch.randn(B, C, device=DEV)
+    xhat = (x.float() - mean) * rstd
+    # per (condition row, channel): beta = -gamma * xhat of one pixel of a frame with that condition -> that pixel's t == +-0 or a
+    # few ulps, and every other pixel's t is an ordinary number
+    beta = torch.empty(B, C, device=DEV)
+    for s in range(B):
+        beta[s] = -(gamma[s] * xhat[s, 3, 5])
+    gb = torch.cat([gamma, beta], 1).contiguous()
+    a = K.cbn_apply(x, C, mean, rstd, gb, samp, True)
+    g = torch.randn(F_, H, W, C, device=DEV).to(dtype)
+    dx, dgb = K.cbn_backward(g, None, x, C, mean, rstd, gb, samp, True)
+    # torch evaluation with the STORED activation as the mask
+    mask = (a.float() > 0).float()
+    gm = g.float() * mask
+    gam_f = gamma[samp.long()].view(F_, 1, 1, C)
+    dgamma = torch.zeros(B, C, device=DEV).index_add_(0, samp.long(), (gm * xhat).sum((1, 2)))
+    dbeta = torch.zeros(B, C, device=DEV).index_add_(0, samp.long(), gm.sum((1, 2)))
+    dxhat = gm * gam_f
+    n = F_ * H * W
+    dx_ref = rstd * (dxhat - dxhat.sum((0, 1, 2)) / n - xhat * (dxhat * xhat).sum((0, 1, 2)) / n)
+    near = int(((gam_f * xhat + beta[samp.long()].view(F_, 1, 1, C)).abs() < 1e-5).sum())
+    assert near >= B * C                                     # the adversarial elements are really there
+    tol = 1e-5 if dtype == torch.float32 else 8e-3           # bf16: rounding of the stored dx only
+    assert float((dx.float() - dx_ref).abs().max()) < tol * float(dx_ref.abs().max() + 1)
+    assert rel(dgb[:, :C], dgamma.cpu()) < 1e-5 and rel(dgb[:, C:], dbeta.cpu()) < 1e-5
