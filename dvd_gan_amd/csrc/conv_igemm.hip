@@ -963,6 +963,7 @@ struct WgK {
     size_t x_bytes, dy_bytes;
     int maxshift, xcd_remap;
     float* dbias;
+    float* wsb;             // row kernel, workspace path: bias partial sums [slice][workgroup][BMc] behind the tile partials
     float* ws;                           // partial tiles [slice][x-block][BMc*BNc] when non-null
 };
 
@@ -1381,13 +1382,23 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) gload1(mk + 32 * s_, ra[s_], rb[s_]);
     };
-    const bool do_bias = p.dbias != nullptr && dyl == 0 && dtl == 0 && tci == 0;   // centre row: the dy tile is tap-independent
+    // Bias gradient = column sums of dy.  The dy tile is tap-independent, so ANY workgroup of a (tco, slice) can sum any of its
+    // 32-pixel sub-steps.  With the slice workspace the KW * tiles_ci workgroups of the centre time slab take the sub-steps in turn
+    // (sub-step n belongs to share n % nshare) and leave their partial sums in the workspace for wgrad_row_bias_reduce_kernel:
+    // when only the centre-row, tci == 0 workgroups summed -- every sub-step, ~16 VALU per 16-byte chunk beside their MFMAs -- they
+    // were the stragglers of the launch (+6...11 % on the large shapes), and their atomics formed one chain per channel.
+    const bool spread = p.ws != nullptr;
+    const bool do_bias = p.dbias != nullptr && dtl == 0 && (spread || (dyl == 0 && tci == 0));
+    const int nshare = spread ? KW * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
+    int bphase = 0;                                              // share of the next sub-step to be stored
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto lstore1 = [&](char* st, const u32x4 (&ra)[NPA], const u32x4 (&rb)[NXL]) __attribute__((always_inline)) {
+        const bool mine = do_bias && bphase == myshare;          // wave-uniform
+        if (++bphase == nshare) bphase = 0;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             *reinterpret_cast<u32x4*>(st + (rra + i * RPPA) * RSA + cka * 16) = ra[i];
-            if (do_bias) {
+            if (mine) {
                 bs[0] += __uint_as_float(ra[i].x << 16); bs[1] += __uint_as_float(ra[i].x & 0xffff0000u);
                 bs[2] += __uint_as_float(ra[i].y << 16); bs[3] += __uint_as_float(ra[i].y & 0xffff0000u);
                 bs[4] += __uint_as_float(ra[i].z << 16); bs[5] += __uint_as_float(ra[i].z & 0xffff0000u);
@@ -1500,7 +1511,8 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
                 float a = 0.f;
                 for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
                 const int co = co0 + tid * 8 + k;
-                if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+                if (spread) p.wsb[((size_t)bz * gridDim.x + bx) * BMc + tid * 8 + k] = a;      // partial of (slice, workgroup)
+                else if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
             }
         }
         __syncthreads();
@@ -1574,6 +1586,42 @@ __global__ void wgrad_row_reduce_kernel(WgRowRedK p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (ci + j < p.Cin_real) d[j * p.s_ci] += a[j];
+}
+
+// bias gradient of the row kernel's workspace path: dbias[co] += sum over (slice, filter row of the centre time slab, ci tile) of the
+// partial column sums, in a fixed order (block = 32 channels x 8 partial lanes)
+struct WgBiasRedK { const float* wsb; float* dbias; int nslice, gx, tiles_co, tiles_ci, KW, kt, BMc, Cout; };
+__global__ __launch_bounds__(1024) void wgrad_row_bias_reduce_kernel(WgBiasRedK p) {
+    // block = 32 channels x 32 partial lanes; a lane walks its items eight loads at a time (a few thousand partials per channel on
+    // the large shapes: as a serial chain on 8 lanes this kernel took ~250 us)
+    __shared__ float red[32][33];
+    const int gpt = p.BMc / 32;
+    const int tco = blockIdx.x / gpt, cg = blockIdx.x - tco * gpt;
+    const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
+    const int tiles = p.tiles_co * p.tiles_ci, per = p.KW * p.tiles_ci, nitem = p.nslice * per;
+    const int irow0 = (p.kt >> 1) * p.KW;
+    auto item = [&](int i) __attribute__((always_inline)) -> float {
+        if (i >= nitem) return 0.f;
+        const int bz = i / per, r = i - bz * per;
+        const int iy = r / p.tiles_ci, tci = r - iy * p.tiles_ci;
+        const int bx = (irow0 + iy) * tiles + tco * p.tiles_ci + tci;
+        return p.wsb[((size_t)bz * p.gx + bx) * p.BMc + cg * 32 + c];
+    };
+    float a = 0.f;
+    for (int i = l; i < nitem; i += 32 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = item(i + 32 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    red[l][c] = a;
+    __syncthreads();
+    if (l == 0) {
+        for (int j = 1; j < 32; ++j) a += red[j][c];
+        const int co = tco * p.BMc + cg * 32 + c;
+        if (co < p.Cout) p.dbias[co] += a;
+    }
 }
 
 // Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
@@ -1913,7 +1961,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
 extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
     WgK p; dim3 grid; int ta, tb, mode; long long msplit;
     if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
-    if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64);
+    if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) + msplit * (long long)grid.x * (ta * 64);   // + bias partials
     return msplit * (long long)grid.x * (ta * 64) * (tb * 64);
 }
 
@@ -1923,6 +1971,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     if (rc != DVD_OK) return rc;
     const int ntaps = d->kt * d->kh * d->kw;
     if (d->ws && msplit > 1) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw
+    p.wsb = (p.ws && mode == 1) ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) : nullptr;
     ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
@@ -1951,6 +2000,10 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
                         p.s_co, p.s_ci, p.s_tap};
             const long long n = (long long)grid.x * r.KW * r.BMc * r.BNc;
             wgrad_row_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
+            if (p.dbias) {
+                WgBiasRedK b{p.wsb, p.dbias, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, d->kw, d->kt, ta * 64, p.Cout};
+                wgrad_row_bias_reduce_kernel<<<p.tiles_co * (ta * 64 / 32), 1024, 0, st>>>(b);
+            }
         }
         return launch_status();
     }

@@ -87,7 +87,8 @@ def main():
         if what in ("wgrad", "all") and not slabs:
             dy = torch.randn(F_, S, S, Cout, device=dev).to(dt)
             dw = torch.zeros(Cout, Cin, k, k, device=dev)
-            ms = bench(lambda: K.conv_wgrad(x, dy, dw, (k, k), Cout, Cin), max(2, iters // 3))
+            db = torch.zeros(Cout, device=dev) if os.environ.get("WG_BIAS") == "1" else None      # bias gradient rides along
+            ms = bench(lambda: K.conv_wgrad(x, dy, dw, (k, k), Cout, Cin, dbias=db), max(2, iters // 3))
             print(f"wgrad M={M:8d} C={Cin:5d} Cout={Cout:5d} k={k}          : {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
 
 
