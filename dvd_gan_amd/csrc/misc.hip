@@ -163,8 +163,10 @@ __global__ __launch_bounds__(256) void linear_bwd_in_kernel(const float* dout, c
     const int b = blockIdx.x, kx = threadIdx.x & 63, jl = threadIdx.x >> 6;
     const int k = blockIdx.y * 64 + kx;
     float a = 0.f;
-    if (k < K)
-        for (int j = jl; j < J; j += 4) a += dout[(size_t)b * J + j] * W[(size_t)j * K + k];
+    if (k < K) {
+#pragma unroll 8
+        for (int j = jl; j < J; j += 4) a += dout[(size_t)b * J + j] * W[(size_t)j * K + k];      // 8 loads in flight: the J / 4 steps are latency
+    }
     red[jl][kx] = a;
     __syncthreads();
     if (jl == 0 && k < K) {
