@@ -107,8 +107,10 @@ typedef struct {
     const void* x;
     const void* dy;
     float* dw;
-    float* dbias;              /* optional: dbias[co] += sum_m dy[m][co] (bias gradient, fused: the centre-tap
-                                  workgroups already stream every dy row), co < Cout; NULL = skip          */
+    float* dbias;              /* optional: dbias[co] += sum_m dy[m][co] (bias gradient, fused: the workgroups of a
+                                  channel tile already stream every dy row and take the 32-row steps in turn; with
+                                  `ws` their partial sums go through the workspace and are added in a fixed order,
+                                  without it the centre-tap workgroups add with atomics), co < Cout; NULL = skip */
     float* ws;                 /* optional workspace of dvd_conv_wgrad_ws_floats(d) floats: row slices write
                                   their partial tiles there with plain stores and a second kernel reduces
                                   them into dw (deterministic, no atomics).  NULL = fp32 atomics on dw      */
