@@ -115,8 +115,11 @@ class Trainer(object):
         # is pending.  DVD_CHAIN_PRIO=1 / 0 forces the high-priority chain on / off.
         prio = os.environ.get("DVD_CHAIN_PRIO", "auto")
         self._chain = None
+        self._aux = None          # stream of the discriminator passes over the real clips (see _train_step)
         if torch.cuda.is_available() and (prio == "1" or (prio == "auto" and self.exchange.world == 1)):
             self._chain = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
+            if self.exchange.world == 1 and os.environ.get("DVD_D_REAL_EARLY", "1") != "0":
+                self._aux = torch.cuda.Stream()
         self.rank = torch.distributed.get_rank() if self.exchange.world > 1 else 0
         self.build_model()
         if self.pretrained_model:
@@ -253,19 +256,40 @@ class Trainer(object):
                                 else torch.as_tensor(draws["z"]), self.device)
             z_class = self.label_sample() if draws is None else to_device_async(self._check_labels(torch.as_tensor(draws["z_class"])), self.device)
             ex.finish("G")
+            early = self._aux is not None
+            if early:
+                # The discriminator passes over the REAL clips need nothing from the generator: they run on a second stream beside
+                # the 4 x 4 / 8 x 8 time loops at the start of the generator forward, the one phase of the step with idle CUs and
+                # no weight-gradient work to fill them.  Same arithmetic in the same per-network order (real before fake, so the
+                # spectral-norm state advances as in the reference); autograd runs their backward nodes on that stream too.
+                cur = torch.cuda.current_stream()
+                self._aux.wait_stream(cur)
+                with torch.cuda.stream(self._aux):
+                    ds_loss_real = self.calc_loss(self.D_s(real_s, real_labels), True)
+                    real_d = vid_downsample(real_videos)
+                    dt_loss_real = self.calc_loss(self.D_t(real_d, real_labels), True)
+                for t_ in (real_s, real_videos, real_labels):
+                    t_.record_stream(self._aux)
             fake_videos = self.G(z, z_class, hidden)
             ids_fake = draw_frame_ids(T, k, fg) if draws is None else torch.as_tensor(draws["perm_fake"])[:k].sort()[0]
             fake_s = sample_k_frames(fake_videos, T, k, ids_fake)
             # ---------------- D_s
-            ds_loss_real = self.calc_loss(self.D_s(real_s, real_labels), True)
+            if early:
+                cur.wait_stream(self._aux)
+                for t_ in (ds_loss_real, dt_loss_real, real_d):
+                    t_.record_stream(cur)
+            else:
+                ds_loss_real = self.calc_loss(self.D_s(real_s, real_labels), True)
             ds_loss_fake = self.calc_loss(self.D_s(fake_s.detach(), z_class), False)
             self.reset_grad()
             (ds_loss_real + ds_loss_fake).backward()
             Fn.join_side()
             ex.start("Ds", self.ds_optimizer.grad)
             # ---------------- D_t (its forward/backward overlaps the D_s gradient exchange)
-            real_d, fake_d = vid_downsample(real_videos), vid_downsample(fake_videos)
-            dt_loss_real = self.calc_loss(self.D_t(real_d, real_labels), True)
+            fake_d = vid_downsample(fake_videos)
+            if not early:
+                real_d = vid_downsample(real_videos)
+                dt_loss_real = self.calc_loss(self.D_t(real_d, real_labels), True)
             dt_loss_fake = self.calc_loss(self.D_t(fake_d.detach(), z_class), False)
             ex.finish("Ds")
             self.ds_optimizer.step()
