@@ -31,7 +31,8 @@ import os as _os
 _SIDE = {"on": False, "stream": None, "serial": _os.environ.get("DVD_SIDE_SERIAL") == "1",      # env: profiling aid, see below
          "cb": False,                                                                           # join callback queued for the running backward
          "defer": False, "queue": [],                                                           # held-back weight-gradient launches
-         "defer_hw": int(_os.environ.get("DVD_DEFER_HW", "16"))}                                # frame extent from which the time loops release them
+         "defer_hw": int(_os.environ.get("DVD_DEFER_HW", "16")),
+         "budget": float(_os.environ.get("DVD_DEFER_TF", "0")) * 1e12, "held": 0.0}                                # frame extent from which the time loops release them
 
 
 def direct_weight_grads(flag):
@@ -92,6 +93,7 @@ def defer_weight_grads(flag):
     gradients only time-share the CUs.  OFF unless DVD_SIDE_DEFER=1: measured 537.9-543.0 ms per step against 535.9-536.0 without
     (round 3, tools/ab_defer.sh) -- the released kernels take every CU and the time loop waits for them."""
     _SIDE["defer"] = bool(flag) and _os.environ.get("DVD_SIDE_DEFER", "0") == "1"
+    _SIDE["held"] = 0.0
     if not _SIDE["defer"]:
         flush_deferred()
 
@@ -107,9 +109,15 @@ def flush_deferred():
             fn()
 
 
-def _side_run(fn, *tensors):
-    """fn() launches weight-gradient kernels: on the side stream now, or later (see defer_weight_grads)."""
-    if _SIDE["defer"] and not _SIDE["serial"]:
+def _side_run(fn, *tensors, cost=None):
+    """fn() launches weight-gradient kernels: on the side stream now, or later (see defer_weight_grads).  cost: FLOPs of the
+    launches; with a budget (DVD_DEFER_TF, TFLOP) only that much work is held back per backward pass, the rest goes out at once."""
+    hold = _SIDE["defer"] and not _SIDE["serial"]
+    if hold and _SIDE["budget"] > 0:
+        hold = cost is not None and _SIDE["held"] + cost <= _SIDE["budget"]
+        if hold:
+            _SIDE["held"] += cost
+    if hold:
         _queue_join()
         _SIDE["queue"].append((fn, [t for t in tensors if t is not None]))
         return
@@ -287,7 +295,7 @@ class Conv(Function):
                     K.sn_backward(G, w, u, v, sigma, out=wp.grad)
                 else:
                     K.conv_wgrad(x, dy, wp.grad, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp)
-            _side_run(wgrad, x, dy, w, sigma)
+            _side_run(wgrad, x, dy, w, sigma, cost=2.0 * dy.numel() / dy.shape[-1] * spec.cout * spec.cin * w[0, 0].numel())
         elif ctx.needs_input_grad[1]:
             G = torch.zeros_like(w)
             if ctx.needs_input_grad[2]:           # bias gradient rides along in the wgrad kernel
