@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const T* __restrict_
 // ----------------------------------------------------------------------------- pooling / resampling
 // y[f][t][y][x][c] = scale * sum over the (pt x 2 x 2) window of x
 template <typename T>
-__global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld, int pt, float scale) {
+__global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld, int pt, float scale, const T* mask) {
     const int cg = ld / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nout * cg) return;
@@ -281,6 +281,12 @@ __global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, in
             }
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] *= scale;
+    if (mask) {          // ReLU mask of the pooled result's own grid (backward of relu -> nearest x2 -> conv): zero where mask <= 0
+        float m[8];
+        load8<T>(mask + (size_t)(i / cg) * ld + g * 8, m);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = m[k] > 0.f ? acc[k] : 0.f;
+    }
     store8<T>(y + (size_t)(i / cg) * ld + g * 8, acc);
 }
 // 2x2x2 max pooling (stride 2) of a channels-last [f][T][H][W][c] tensor: Module/Attention.py:148 (nn.MaxPool3d(2, 2)).
@@ -563,7 +569,16 @@ extern "C" int dvd_pool(int dtype, const void* x, void* y, long long frames, int
     if (!x || !y || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || (pt != 1 && pt != 2)) return DVD_E_ARG;
     if (ld & 7) return DVD_E_SHAPE;
     const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
-    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale));
+    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale, (const T*)nullptr));
+    return launch_status();
+}
+// the same with a ReLU mask on the OUTPUT grid (same layout and leading dimension as y): y = mask > 0 ? pooled : 0
+extern "C" int dvd_pool_masked(int dtype, const void* x, const void* mask, void* y, long long frames, int To, int Ho, int Wo, int ld,
+                               int pt, float scale, void* stream) {
+    if (!x || !y || !mask || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || (pt != 1 && pt != 2)) return DVD_E_ARG;
+    if (ld & 7) return DVD_E_SHAPE;
+    const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
+    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale, (const T*)mask));
     return launch_status();
 }
 // 2x2x2 max pooling; output grid frames x To x Ho x Wo (input 2To x 2Ho x 2Wo)

@@ -276,9 +276,7 @@ class Conv(Function):
         if ctx.needs_input_grad[0]:
             if spec.up2:
                 dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip)
-                dx = K.pool(dx, 1, scale=1.0)                 # transpose of nearest x2
-                if spec.relu_in:
-                    dx = K.act_backward(dx, x, L.ACT_RELU)
+                dx = K.pool(dx, 1, scale=1.0, mask=x if spec.relu_in else None)      # transpose of nearest x2 (+ ReLU mask)
             else:
                 dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None)
         wp, bp = ctx.params

@@ -237,13 +237,18 @@ def _grid4(x):
     return x.shape[0], 1, x.shape[1], x.shape[2]
 
 
-def pool(x, pt=1, scale=None):
-    """(pt,2,2) window sum * scale (default: average)."""
+def pool(x, pt=1, scale=None, mask=None):
+    """(pt,2,2) window sum * scale (default: average); mask (shape of the result): zero where mask <= 0."""
     F_, T, H, W = _grid4(x)
     To, Ho, Wo = T // pt, H // 2, W // 2
     scale = (1.0 / (4 * pt)) if scale is None else scale
     shape = (F_, To, Ho, Wo, x.shape[-1]) if x.dim() == 5 else (F_, Ho, Wo, x.shape[-1])
     y = torch.empty(shape, dtype=x.dtype, device=x.device)
+    if mask is not None:
+        assert mask.shape == y.shape and mask.dtype == y.dtype
+        L.check(L.lib().dvd_pool_masked(L.dt(x), L.ptr(x), L.ptr(mask), L.ptr(y), _ll(F_), To, Ho, Wo, x.shape[-1], pt, _f(scale),
+                                        L.stream()))
+        return y
     L.check(L.lib().dvd_pool(L.dt(x), L.ptr(x), L.ptr(y), _ll(F_), To, Ho, Wo, x.shape[-1], pt, _f(scale), L.stream()))
     return y
 

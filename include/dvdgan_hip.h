@@ -211,6 +211,10 @@ int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, const void* 
  * F.avg_pool2d / F.avg_pool3d at Discriminators.py:197,206,225,249,352,361,380,408 and the
  * gradient of F.interpolate(scale_factor=2) (GResBlock.py:55,72). Output grid given. */
 int dvd_pool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt, float scale, void* stream);
+/* ... followed by a ReLU mask on the output grid (mask: same layout as y): the backward of relu -> nearest x2 -> conv
+ * (GResBlock.py:52-57) in one pass instead of a pooling pass plus a masking pass */
+int dvd_pool_masked(int dtype, const void* x, const void* mask, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt,
+                    float scale, void* stream);
 int dvd_unpool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt, float scale, void* stream);
 int dvd_colsum(int dtype, const void* x, long long rows, int C, int ld, float* out /* += */, void* stream);
 int dvd_add(int dtype, const void* a, const void* b, void* out, long long n, void* stream);
