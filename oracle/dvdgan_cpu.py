@@ -9,7 +9,7 @@ reference implements in /root/reference (file:line cited per function).  State l
 dicts keyed exactly like the reference `state_dict()`s, so reference checkpoints and the golden
 vectors in tests/golden/ (generated from the real reference by tests/golden/make_golden.py)
 plug straight in.  Parity is PINNED: tests/test_oracle_golden.py checks every function below
-against those vectors (F1..F10 of SURVEY.md section 8c).
+against those vectors (F1..F10 of SURVEY.md section 8c, F11..F16 added by later rounds).
 
 All reference quirks are reproduced on purpose (SURVEY.md section 8a notes 1-6):
   * SN power iteration advances u/v on every forward, also in eval / no_grad;
@@ -366,13 +366,16 @@ def snapshot_grads(st):
     return snaps
 
 
-def train_step(st, real_videos, real_labels, z, z_class, perm_real, perm_fake, rec=None, d_iters=1):
+def train_step(st, real_videos, real_labels, z, z_class, perm_real, perm_fake, rec=None, d_iters=1, hidden=None):
     """trainer.py:213-307.  real_videos: [B,3,T,H,W]; RNG draws are passed in the order the reference consumes them:
     perm_real, z, z_class, perm_fake -- for d_iters > 1 (the loop of trainer.py:230) each of the four is a sequence with one
     entry per discriminator iteration; the generator step uses the clips of the LAST iteration (trainer.py:296-297).
     Returns the six loss terms [ds_real, ds_fake, dt_real, dt_fake, g_s, g_t] (discriminator terms of the last iteration).
     rec (test aid): a dict that receives the generator taps (`generator(..., taps=)`), the generated clips and the six
-    raw discriminator outputs, for teacher-forced comparisons of single modules."""
+    raw discriminator outputs, for teacher-forced comparisons of single modules.
+    hidden (frame-conditional variant, BASELINE configs[4]): initial ConvGRU states handed to `generator(hidden=)` in every
+    generator forward of the step (ConvGRU.py:104-118); leaves with requires_grad receive their gradient from the generator
+    update's backward pass (the discriminator updates see detached clips).  Pinned by golden F15."""
     taps = [] if rec is not None else None
     real = real_videos.permute(0, 2, 1, 3, 4).contiguous()                      # :227
     if d_iters == 1:
@@ -382,7 +385,7 @@ def train_step(st, real_videos, real_labels, z, z_class, perm_real, perm_fake, r
             del taps[:]
         real_s = sample_k_frames(real, frame_ids_from_perm(perm_real[it], st.k))       # :233
         zc = z_class[it]
-        fake = generator(st.G, z[it], zc, st.ch, st.T, st.latent_dim, taps=taps)       # :239
+        fake = generator(st.G, z[it], zc, st.ch, st.T, st.latent_dim, taps=taps, hidden=hidden)      # :239
         fake_s = sample_k_frames(fake, frame_ids_from_perm(perm_fake[it], st.k))       # :242
         # ---- D_s ----                                                             :243-253
         o_sr, o_sf = spatial_disc(st.Ds, real_s, real_labels), spatial_disc(st.Ds, fake_s.detach(), zc)

@@ -42,6 +42,26 @@ def from_bf16_bits(a):
     return (a.astype(np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
 
 
+def latent_dim_of(g):
+    """Generator latent_dim of a trainer fixture (frames are 16 * latent_dim pixels; 4 unless the fixture says otherwise)."""
+    return int(g["meta.latent_dim"]) if "meta.latent_dim" in g else 4
+
+
+def fixture_hidden(g):
+    """Initial ConvGRU states of a `meta.hidden` fixture (F15): per ConvGRU the list of per-layer numpy arrays
+    [B, hidden_l, S, S] -- the closed forms `hidden.<gru>.<layer>` of synth.py, scale 0.5, as make_golden.py installed them."""
+    sys.path.insert(0, GOLDEN)
+    import synth
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    ld = latent_dim_of(g)
+    out = []
+    for gi in range(4):
+        c = (8 * ch, 16 * ch, 8 * ch) if gi < 3 else (4 * ch, 8 * ch, 4 * ch)
+        S = ld << gi
+        out.append([synth.uniform(f"hidden.{gi}.{l}", (B, c[l], S, S), 0.5) for l in range(3)])
+    return out
+
+
 def full_states(g):
     """Initial state_dicts (numpy) of G / D_s / D_t for a trainer fixture: stored entries verbatim, large tensors of a
     `meta.synth` fixture from the closed forms of tests/golden/synth.py (the generating script installed the same values
@@ -58,7 +78,8 @@ def full_states(g):
         return [sub(g, tag + ".sd0") for tag in ("G", "Ds", "Dt")]
     import torch
     with torch.device("meta"):                       # shapes only: no initialisation work
-        nets = (Generator(z_dim, 4, n_class, ch, T), SpatialDiscriminator(ch, n_class), TemporalDiscriminator(ch, n_class))
+        nets = (Generator(z_dim, latent_dim_of(g), n_class, ch, T), SpatialDiscriminator(ch, n_class),
+                TemporalDiscriminator(ch, n_class))
     out = []
     for net, tag in zip(nets, ("G", "Ds", "Dt")):
         tmpl = {kk: tuple(v.shape) for kk, v in net.state_dict().items()}
@@ -67,7 +88,7 @@ def full_states(g):
 
 
 def fixture_real(g, i):
-    """Input clips [B,3,T,64,64] of batch i of a trainer fixture (stored, or the closed form for `meta.synth` fixtures)."""
+    """Input clips [B,3,T,S,S] of batch i of a trainer fixture (stored, or the closed form for `meta.synth` fixtures)."""
     if f"in.real.{i}" in g:
         return g[f"in.real.{i}"]
     if f"in.realb.{i}" in g:
@@ -75,4 +96,5 @@ def fixture_real(g, i):
     sys.path.insert(0, GOLDEN)
     import synth
     ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
-    return synth.uniform(f"real.{i}", (B, 3, T, 64, 64))
+    fr = 16 * latent_dim_of(g)
+    return synth.uniform(f"real.{i}", (B, 3, T, fr, fr))

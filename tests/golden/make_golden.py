@@ -362,8 +362,39 @@ def f8_helpers(R):
 
 
 # ----------------------------------------------------------------------------- F9 / F10
+def conditional_generator_forward(G, hid):
+    """-> a forward(z, class_id) for the REFERENCE generator `G` that does what Generator.forward (Generator.py:63-120) does with
+    ONE change: the first frame of ConvGRU number n is evaluated as `conv(x_0, hid[n])` instead of `conv(x_0)` -- the hook
+    ConvGRU.forward(x, hidden) offers (ConvGRU.py:104-118); frame-conditional variant, BASELINE configs[4].  Every layer is
+    the reference's own module; with hid[n] = None the result is that of the unmodified forward (asserted by the caller)."""
+    import torch.nn.functional as F
+
+    def forward(z, class_id):
+        T = G.n_frames
+        cond = torch.cat((z, G.embedding(class_id)), dim=1)
+        y = G.affine_transfrom(cond).view(-1, 8 * G.ch, G.latent_dim, G.latent_dim)
+        n = 0
+        for k, m in enumerate(G.conv):
+            if hasattr(m, "cells"):                                  # ConvGRU
+                if k > 0:
+                    y = y.view(-1, T, *y.shape[1:])
+                state, outs = hid[n], []
+                n += 1
+                for i in range(T):
+                    state = m(y if k == 0 else y[:, i], state)
+                    outs.append(state[-1])
+                y = torch.stack(outs, 1)
+                y = y.reshape(-1, *y.shape[2:])
+            else:                                                    # GResBlock: condition rows t-major (quirk 1)
+                y = m(y, cond.repeat(T, 1))
+        y = torch.tanh(G.colorize(F.relu(y)))
+        return y.view(-1, T, *y.shape[1:])
+    return forward
+
+
 def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr=5e-5,
-                grads_of=(), n_batches=None, synth_big=False, grad_head=None, d_iters=1, bf16_state=False):
+                grads_of=(), n_batches=None, synth_big=False, grad_head=None, d_iters=1, bf16_state=False,
+                latent_dim=4, hidden=False):
     """Drive the unmodified reference Trainer.train() (trainer.py:189-307) on CPU and
     record every RNG draw, the six loss terms per step, named gradients and parameter
     checksums at each optimizer.step().
@@ -375,7 +406,12 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
     runs, and stored as 2-byte values ('<tag>.sd0b.<key>', 'in.realb.<i>': the upper halves of the float32 words) -- a bf16
     implementation then starts from exactly the reference's operands, and the fixture stays small.
     d_iters > 1 (trainer.py:230): the draws of discriminator iteration i of step s are stored as in.<name>.<s>.<i>; losses,
-    gradients and checksums are those of the LAST discriminator iteration of the step (and of the generator update)."""
+    gradients and checksums are those of the LAST discriminator iteration of the step (and of the generator update).
+    latent_dim != 4 (frames of 16 * latent_dim pixels): trainer.py:349 never passes latent_dim, so the Trainer's generator is
+    replaced by the reference Generator(latent_dim=...) and `select_opt_schr` re-run before training (meta.latent_dim).
+    hidden: initial ConvGRU states (closed forms of synth.py, `hidden.<gru>.<layer>`, scale 0.5) supplied at the first frame
+    of every ConvGRU through `conditional_generator_forward`; their gradients at the generator update are stored as
+    `hgrad.<step>.<gru>.<layer>` (head) and `out.hgsum.<step>` (|.| checksums)."""
     import trainer as TR
     import synth
     import torch.nn as nn
@@ -392,15 +428,34 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
         gpus=[], parallel=False)
     gen = torch.Generator().manual_seed(seed + 1)
     nb_ = steps if n_batches is None else n_batches
+    FR = 16 * latent_dim
     if synth_big:
-        loader = [(torch.from_numpy(synth.uniform(f"real.{i}", (B, 3, T, 64, 64))),
+        loader = [(torch.from_numpy(synth.uniform(f"real.{i}", (B, 3, T, FR, FR))),
                    torch.randint(0, n_class, (B,), generator=gen)) for i in range(nb_)]
     else:
-        loader = [((torch.rand(B, 3, T, 64, 64, generator=gen) * 2 - 1),
+        loader = [((torch.rand(B, 3, T, FR, FR, generator=gen) * 2 - 1),
                    torch.randint(0, n_class, (B,), generator=gen)) for _ in range(nb_)]
     if bf16_state:
         loader = [(v.to(torch.bfloat16).float(), l) for v, l in loader]
     tr = TR.Trainer(loader, cfg)
+    if latent_dim != 4:
+        tr.G = R.GE.Generator(z_dim, latent_dim, n_class=n_class, ch=ch, n_frames=T)
+        tr.select_opt_schr()
+    hid = None
+    if hidden:
+        hid = []
+        for gi, m in enumerate(mm for mm in tr.G.conv if hasattr(mm, "cells")):
+            S_ = latent_dim << gi
+            hid.append([torch.from_numpy(synth.uniform(f"hidden.{gi}.{l}", (B, m.hidden_sizes[l], S_, S_), 0.5)).requires_grad_(True)
+                        for l in range(m.n_layers)])
+        with torch.no_grad():                    # the restated forward equals the reference's own when no state is supplied
+            import copy
+            Gc = copy.deepcopy(tr.G)
+            zz, cc = torch.randn(B, z_dim, generator=gen), torch.randint(0, n_class, (B,), generator=gen)
+            a = copy.deepcopy(Gc)(zz, cc)
+            b = conditional_generator_forward(Gc, [None] * len(hid))(zz, cc)
+            assert torch.equal(a, b), "conditional_generator_forward deviates from Generator.forward"
+        tr.G.forward = conditional_generator_forward(tr.G, hid)
     st = {}
     for net, tag in ((tr.G, "G"), (tr.D_s, "Ds"), (tr.D_t, "Dt")):
         for kk, v in net.state_dict().items():
@@ -436,6 +491,7 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
         r = o_calc(x, flag); losses.append(float(r)); return r
     tr.calc_loss = w_calc
     snaps = {"Ds": [], "Dt": [], "G": []}
+    hgrads = []
 
     def wrap_opt(opt, net, tag):
         o_step = opt.step
@@ -445,6 +501,11 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
                  for kk, p in net.named_parameters() if p.grad is not None and kk in grads_of}
             gsum = {kk: float(p.grad.double().abs().sum()) for kk, p in net.named_parameters()
                     if p.grad is not None}
+            if tag == "G" and hid is not None:
+                hgrads.append([[npy(h.grad) for h in hs] for hs in hid])
+                for hs in hid:
+                    for h in hs:
+                        h.grad = None
             r = o_step(*a, **kw)
             psum = {kk: float(v.double().abs().sum()) for kk, v in net.state_dict().items()}
             snaps[tag].append((g, gsum, psum))
@@ -486,6 +547,15 @@ def run_trainer(R, *, adv_loss, ch, T, k, B, n_class, steps, seed, z_dim=120, lr
             keys = sorted(psum)
             st[f"meta.psum_keys.{tag}"] = np.array(keys)
             st[f"out.psum.{s}.{tag}"] = np.array([psum[kk] for kk in keys])
+    for s, hg in enumerate(hgrads):
+        sums = []
+        for gi, hs in enumerate(hg):
+            for l, v in enumerate(hs):
+                st[f"hgrad.{s}.{gi}.{l}"] = v if grad_head is None else v.reshape(-1)[:grad_head]
+                sums.append(float(np.abs(v.astype(np.float64)).sum()))
+        st[f"out.hgsum.{s}"] = np.array(sums)
+    st["meta.latent_dim"] = np.array(latent_dim)
+    st["meta.hidden"] = np.array(int(bool(hidden)))
     put_state(st, "G.sd1", tr.G)
     put_state(st, "Ds.sd1", tr.D_s)
     put_state(st, "Dt.sd1", tr.D_t)
@@ -582,6 +652,36 @@ def f14_default_init_bf16(R):
     save("f14_default_init_bf16", keep)
 
 
+F15_NAMES = ("conv.0.cells.0.update_gate.weight", "conv.0.cells.1.reset_gate.weight", "conv.3.cells.2.out_gate.weight",
+             "conv.6.cells.1.update_gate.bias", "conv.9.cells.2.out_gate.weight", "conv.9.cells.0.reset_gate.weight",
+             "conv.1.conv0.module.weight_bar", "conv.11.conv1.module.weight_bar", "conv.10.CBNorm2.embed.weight",
+             "embedding.weight", "affine_transfrom.weight", "colorize.module.weight_bar",
+             "pre_conv.0.module.weight_bar", "attn.gamma", "self_attn.gamma", "linear.module.weight_bar",
+             "res3d.conv1.module.weight_bar", "conv1.conv_sc.module.weight_bar")
+
+
+def f15_state_carry(R):
+    """BASELINE configs[4] as a STEP: two steps of the reference Trainer with initial ConvGRU states supplied at the first
+    frame of every ConvGRU (ConvGRU.py:104-118 through `conditional_generator_forward`), T=12 (D_t pools to T'=3), 128x128
+    frames (latent_dim 8), ch=2, k=4, B=2, 3 classes, hinge, lr 2e-3.  Clips, large weights and the twelve states are
+    synth.py closed forms; stored: draws, losses, named gradients, |grad| checksums, the state gradients (heads + checksums),
+    post-step SN / BN state."""
+    st = run_trainer(R, adv_loss="hinge", ch=2, T=12, k=4, B=2, n_class=3, steps=2, seed=180, z_dim=16, lr=2e-3,
+                     grads_of=F15_NAMES, synth_big=True, grad_head=8192, latent_dim=8, hidden=True)
+    keep = {k: v for k, v in st.items() if not (".sd1." in k and v.size >= 4096)}
+    save("f15_state_carry", keep)
+
+
+def f16_full_width_128(R):
+    """ONE step of the reference Trainer at BASELINE configs[3]'s per-clip shape: ch=32, T=48, 128x128 (latent_dim 8),
+    600 classes, k=8, hinge, lr 5e-5, B=1 -- the real 128..1024-channel widths on the 8x8 .. 128x128 grids.  Same storage
+    scheme as F11."""
+    st = run_trainer(R, adv_loss="hinge", ch=32, T=48, k=8, B=1, n_class=600, steps=1, seed=190, z_dim=120, lr=5e-5,
+                     grads_of=F11_NAMES, synth_big=True, grad_head=8192, latent_dim=8)
+    keep = {k: v for k, v in st.items() if not (".sd1." in k and v.size >= 4096)}
+    save("f16_full_width_128", keep)
+
+
 def f12_ucf101_reader(R):
     """Real-data input path: a tiny synthetic UCF-101-style JPEG folder (2 classes, 3 videos of 9-14 frames, 40x30 pixels)
     read through the reference's UCF101 dataset (Dataloader/datasets/ucf101.py) with the training transforms main.py:42-55
@@ -645,7 +745,8 @@ def f12_ucf101_reader(R):
 ALL = {"f1": f1_spectral_norm, "f2": f2_conditional_norm, "f3": f3_gresblock, "f4": f4_convgru,
        "f5": f5_attention, "f6": f6_generator, "f7": f7_discriminators, "f8": f8_helpers,
        "f9": f9_trainer_steps, "f10": f10_config1, "f11": f11_full_width,
-       "f12": f12_ucf101_reader, "f13": f13_two_d_iters, "f14": f14_default_init_bf16}
+       "f12": f12_ucf101_reader, "f13": f13_two_d_iters, "f14": f14_default_init_bf16,
+       "f15": f15_state_carry, "f16": f16_full_width_128}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -23,7 +23,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, fixture_real, full_states, sub
+from conftest import ROOT, fixture_real, full_states, latent_dim_of, sub
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -59,7 +59,7 @@ def cfg_of(g, lr=None):
 
 def make_trainer(g, dtype):
     from dvd_gan_amd.train_step import Trainer
-    tr = Trainer([], cfg_of(g), device=torch.device(DEV), compute_dtype=dtype)
+    tr = Trainer([], cfg_of(g), device=torch.device(DEV), compute_dtype=dtype, latent_dim=latent_dim_of(g))
     for net, sd in zip((tr.G, tr.D_s, tr.D_t), full_states(g)):
         net.load_state_dict({kk: torch.as_tensor(v) for kk, v in sd.items()})
         net.train()
@@ -82,14 +82,17 @@ def snapshot_hip_grads(tr):
 
 
 # ------------------------------------------------------------------------------------------ exact mode vs the reference
-def test_exact_step_matches_reference_at_full_width(golden):
-    g = golden("f11_full_width")
+@pytest.mark.parametrize("fixture", ["f11_full_width", "f16_full_width_128"])
+def test_exact_step_matches_reference_at_full_width(golden, fixture):
+    """f11: 48 x 64 x 64, 101 classes, B=2 (BASELINE configs[1] / [2]); f16: 48 x 128 x 128, 600 classes, B=1 (configs[3])."""
+    g = golden(fixture)
+    NUMBERS_ = NUMBERS.setdefault(fixture, {})
     tr = make_trainer(g, torch.float32)
     snaps = snapshot_hip_grads(tr)
     losses = [float(v.detach()) for v in tr.train_step(torch.as_tensor(fixture_real(g, 0)), torch.as_tensor(g["in.labels.0"]),
                                                       draws_of(g))]
-    NUMBERS["exact.losses"] = losses
-    NUMBERS["exact.losses_ref"] = [float(v) for v in g["out.losses.0"]]
+    NUMBERS_["exact.losses"] = losses
+    NUMBERS_["exact.losses_ref"] = [float(v) for v in g["out.losses.0"]]
     np.testing.assert_allclose(losses, g["out.losses.0"], rtol=2e-3, atol=2e-4)
     worst = {}
     for tag in ("Ds", "Dt", "G"):
@@ -105,7 +108,7 @@ def test_exact_step_matches_reference_at_full_width(golden):
             worst[tag + "." + kk] = r
             if np.abs(v).max() > 1e-4 * np.abs(ref).max() / max(v.size, 1):
                 assert r < 1e-2, (tag, kk, r)
-    NUMBERS["exact.grad_worst"] = worst
+    NUMBERS_["exact.grad_worst"] = worst
     for tag, net in (("G", tr.G), ("Ds", tr.D_s), ("Dt", tr.D_t)):          # SN u / v and BN statistics after the step
         sd = net.state_dict()
         for kk, v in sub(g, tag + ".sd1").items():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import fixture_real, full_states, sub
+from conftest import fixture_hidden, fixture_real, full_states, latent_dim_of, sub
 from oracle import dvdgan_cpu as O
 
 RTOL, ATOL = 1e-5, 1e-6
@@ -326,5 +326,42 @@ def test_f14_default_init_step(golden):
         np.testing.assert_allclose(got, g[f"out.gsum.0.{tag}"], rtol=2e-3, atol=1e-9, err_msg=f"{tag} gradient checksums")
         for kk, v in sub(g, f"grad.0.{tag}").items():
             close(snaps[tag][kk].reshape(-1)[:v.size], v, 2e-3, 1e-7, what=f"{tag} grad {kk}")
+    for tag, sd in (("G", st.G), ("Ds", st.Ds), ("Dt", st.Dt)):
+        check_state(sd, sub(g, tag + ".sd1"), 1e-3)
+
+
+# ------------------------------------------------------------------ F15: state carry as a full step (BASELINE configs[4])
+def test_f15_state_carry_steps(golden):
+    """The oracle's `train_step(hidden=)` against two steps of the reference Trainer whose generator received initial ConvGRU
+    states at the first frame of every ConvGRU (ConvGRU.py:104-118): T=12, 128x128 frames, ch=2, k=4, B=2.  Losses, the
+    |grad| checksums of every parameter, the named gradients, the gradients wrt the twelve supplied states and the post-step
+    SN / BN state."""
+    g = golden("f15_state_carry")
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    assert int(g["meta.hidden"]) == 1 and latent_dim_of(g) == 8 and T == 12
+    lr = float(g["meta.lr"])
+    sds = full_states(g)
+    st = O.TrainState(O.make_state(sds[0]), O.make_state(sds[1]), O.make_state(sds[2]), ch=ch, n_frames=T, k_sample=k,
+                      n_class=n_class, z_dim=z_dim, latent_dim=8, adv="hinge", g_lr=lr, d_lr=lr)
+    hidden = [[t(h).requires_grad_(True) for h in hs] for hs in fixture_hidden(g)]
+    for s in range(steps):
+        snaps = O.snapshot_grads(st) if s == 0 else snaps
+        losses = O.train_step(st, t(fixture_real(g, s)), t(g[f"in.labels.{s}"]), t(g[f"in.z.{s}"]), t(g[f"in.z_class.{s}"]),
+                              g[f"in.perm_real.{s}"], g[f"in.perm_fake.{s}"], hidden=hidden)
+        np.testing.assert_allclose(losses, g[f"out.losses.{s}"], rtol=2e-4, atol=2e-5, err_msg=f"losses step {s}")
+        for tag in ("Ds", "Dt", "G"):
+            keys = [str(x) for x in g[f"meta.gsum_keys.{tag}"]]
+            got = np.array([float(snaps[tag][kk].double().abs().sum()) for kk in keys])
+            np.testing.assert_allclose(got, g[f"out.gsum.{s}.{tag}"], rtol=2e-3, atol=1e-9, err_msg=f"{tag} checksums step {s}")
+            for kk, v in sub(g, f"grad.{s}.{tag}").items():
+                close(snaps[tag][kk].reshape(-1)[:v.size], v, 2e-3, 1e-7, what=f"{tag} grad {kk} step {s}")
+        sums = []
+        for gi, hs in enumerate(hidden):
+            for l, h in enumerate(hs):
+                v = g[f"hgrad.{s}.{gi}.{l}"]
+                close(h.grad.reshape(-1)[:v.size], v, 2e-3, 1e-8, what=f"d/dh0 gru {gi} layer {l} step {s}")
+                sums.append(float(h.grad.double().abs().sum()))
+                h.grad = None
+        np.testing.assert_allclose(sums, g[f"out.hgsum.{s}"], rtol=2e-3)
     for tag, sd in (("G", st.G), ("Ds", st.Ds), ("Dt", st.Dt)):
         check_state(sd, sub(g, tag + ".sd1"), 1e-3)
