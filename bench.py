@@ -258,7 +258,9 @@ def main():
                 "step_frac": round(value / world * F / 1e3 / peak, 4) if F else None}
     if rank == 0:
         cfg_id = 1 if a.size == 64 else (4 if a.state_carry else 3)
-        kind = "UCF-101" if a.size == 64 else "Kinetics-600"
+        # configs[1] / [2]: UCF-101-shaped; configs[3]: Kinetics-600-shaped; configs[4]: the frame-conditional video-prediction
+        # variant (BASELINE names no dataset for it)
+        kind = "UCF-101" if a.size == 64 else ("frame-conditional video-prediction" if a.state_carry else "Kinetics-600")
         out = {"metric": "clips/sec per G+Ds+Dt step, 48x64x64 UCF-101 synth" if (a.size == 64 and a.frames == 48)
                else f"clips/sec per G+Ds+Dt step, {a.frames}x{a.size}x{a.size} {kind}-shaped synth",
                "value": round(value, 3), "unit": "clips/s",

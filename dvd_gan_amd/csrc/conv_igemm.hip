@@ -57,7 +57,6 @@ struct ConvK {
     int up2, relu_in, act, out_f32;
     int nmajor;                          // tile order: consecutive workgroups (one XCD's run) share the N tile, not the M tile
     int pm;                              // > 0 (tap-by-tap kernel, small frames): GEMM rows in PIXEL-major order, pm = frames (see conv_igemm_kernel)
-    int dbg;                             // measurement aid (DVD_DBG_EPI): 1 = skip the epilogue (results are garbage), 2 = skip the main loop
     size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
     int maxshift;                        // largest |tap shift| in rows
     GruEpi g;                            // optional fused ConvGRU gate epilogue (mode 0 = off)
@@ -227,7 +226,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
         return (rr >= 0 && ok) ? (unsigned)rr * (ld * eb) + (unsigned)c * eb : kOOB;
     };
     const int mode = p.g.mode;
-    if (p.dbg & 1) return;
+#ifdef DVD_EXP_NOEPI           // compile-time measurement variant (tools/build_variant.sh): the epilogue is skipped, results are garbage
+    return;
+#endif
     if (mode == 1) {                // [u|r] = sigmoid(acc + gx);  hr = h_prev * r        (ConvGRU.py:47-49)
         constexpr int D = kB ? 3 : 1;
         const int h = p.g.h;
@@ -599,7 +600,12 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     }
 
     const int arow = wm * (TM * 32) + (lane & 31), brow = wn * 64 + (lane & 31);
-    if (k_begin < k_end && !(p.dbg & 2)) {
+#ifdef DVD_EXP_NOMAIN          // compile-time measurement variant: the main loop is skipped
+    constexpr bool kMain = false;
+#else
+    constexpr bool kMain = true;
+#endif
+    if (kMain && k_begin < k_end) {
         // 3-stage ring, two tiles in flight.  Waits are COUNTED (vmcnt(NA+2) keeps the youngest tile's
         // DMAs outstanding) and the barrier is the raw s_barrier: __syncthreads() would make hipcc drain
         // vmcnt(0) while an LDS-DMA is pending and collapse the pipeline to depth 1.
@@ -808,7 +814,11 @@ __device__ __forceinline__ void conv_halo_tile(const ConvK& p, char* const smem,
     const int px = l31 & 15, py0 = wm * (TM * 2) + (l31 >> 4);
     constexpr int TMSTRIDE = (UP2 ? 1 : 2) * PITCH * 64;
     const int brow = wn * 64 + l31;
-    const int nsteps = (p.dbg & 2) ? 0 : (oc_end - oc_begin) * ntap2;
+#ifdef DVD_EXP_NOMAIN
+    const int nsteps = 0;
+#else
+    const int nsteps = (oc_end - oc_begin) * ntap2;
+#endif
     if (nsteps > 0) {
 #define VMCNT(n) (((n) & 0xf) | (7 << 4) | (0xf << 8) | (((n) >> 4) << 14))
         constexpr int FL = NSTAGE - 2;                         // weight tiles allowed to stay in flight past tile s+1
@@ -1792,7 +1802,6 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};
     p.nmajor = 0;
-    { static const int dbg = getenv("DVD_DBG_EPI") ? atoi(getenv("DVD_DBG_EPI")) : 0; p.dbg = dbg; }
     {   // extents of the two buffer descriptors (32-bit byte offsets): tensors must stay below 4 GiB
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
         const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;

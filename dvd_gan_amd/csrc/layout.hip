@@ -120,20 +120,7 @@ extern "C" int dvd_clip_to_tensor(const unsigned char* src, const unsigned char*
     return launch_status();
 }
 
-// A HIP stream whose kernels run on the compute units of `mask` only (bit i of word i / 32 = CU i; nwords 32-bit words).
-extern "C" int dvd_stream_create_cumask(const unsigned* mask, int nwords, void** stream) {
-    if (!mask || nwords <= 0 || !stream) return DVD_E_ARG;
-    hipStream_t s = nullptr;
-    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask) != hipSuccess) { (void)hipGetLastError(); return DVD_E_LAUNCH; }
-    *stream = (void*)s;
-    return DVD_OK;
-}
-extern "C" int dvd_stream_destroy(void* stream) {
-    if (!stream) return DVD_E_ARG;
-    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? DVD_OK : DVD_E_LAUNCH;
-}
-
-extern "C" int dvd_abi_version(void) { return 8; }
+extern "C" int dvd_abi_version(void) { return 9; }
 extern "C" const char* dvd_strerror(int code) {
     switch (code) {
         case DVD_OK: return "ok";

@@ -255,9 +255,11 @@ __global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const T* __restrict_
 }
 
 // ----------------------------------------------------------------------------- pooling / resampling
-// y[f][t][y][x][c] = scale * sum over the (pt x 2 x 2) window of x
+// y[f][t][y][x][c] = scale * sum over the (pt x 2 x 2) window of x.  Input grid Ti x Hi x Wi with Ti = To * pt, Hi / 2 = Ho, Wi / 2 = Wo:
+// an odd Hi / Wi loses its last line / column, like F.avg_pool2d's floor (a 3 x 3 map pools to 1 x 1 in D_t at 96 x 96 frames)
 template <typename T>
-__global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld, int pt, float scale, const T* mask) {
+__global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int Hi, int Wi, int ld, int pt, float scale,
+                            const T* mask) {
     const int cg = ld / 8;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nout * cg) return;
@@ -267,7 +269,7 @@ __global__ void pool_kernel(const T* x, T* y, long long nout, int To, int Ho, in
     const int yo = (int)(r % Ho); r /= Ho;
     const int to = (int)(r % To);
     const long long f = r / To;
-    const int Ti = To * pt, Hi = Ho * 2, Wi = Wo * 2;
+    const int Ti = To * pt;
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
@@ -345,7 +347,8 @@ __global__ void maxpool3d_bwd_kernel(const T* x, const T* dy, T* dx, long long n
         store8<T>(dx + ((((size_t)f * Ti + to * 2 + (w >> 2)) * Hi + yo * 2 + ((w >> 1) & 1)) * Wi + xo * 2 + (w & 1)) * ld + g * 8, o);
     }
 }
-// y[f][t][y][x][c] = scale * x[f][t/pt][y/2][x/2][c]
+// y[f][t][y][x][c] = scale * x[f][t/pt][y/2][x/2][c]; the last line / column of an odd output grid lies outside every pooling
+// window (floor) and is zero
 template <typename T>
 __global__ void unpool_kernel(const T* x, T* y, long long nout, int To, int Ho, int Wo, int ld, int pt, float scale) {
     const int cg = ld / 8;
@@ -359,9 +362,14 @@ __global__ void unpool_kernel(const T* x, T* y, long long nout, int To, int Ho, 
     const long long f = r / To;
     const int Ti = To / pt, Hi = Ho / 2, Wi = Wo / 2;
     float v[8];
-    load8<T>(x + ((((size_t)f * Ti + to / pt) * Hi + yo / 2) * Wi + xo / 2) * ld + g * 8, v);
+    if (yo / 2 < Hi && xo / 2 < Wi) {
+        load8<T>(x + ((((size_t)f * Ti + to / pt) * Hi + yo / 2) * Wi + xo / 2) * ld + g * 8, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] *= scale;
+        for (int k = 0; k < 8; ++k) v[k] *= scale;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    }
     store8<T>(y + (size_t)(i / cg) * ld + g * 8, v);
 }
 
@@ -563,13 +571,14 @@ extern "C" int dvd_cbn_backward(int dtype, const void* g, const void* a, const v
     return dvd_cbn_backward_apply(dtype, g, a, x, dx, frames, P, C, ld, mean, rstd, gb, samp, s12, frames * P, relu, stream);
 }
 
-// y = scale * sum over (pt,2,2) windows; output grid frames x To x Ho x Wo
-extern "C" int dvd_pool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt,
+// y = scale * sum over (pt,2,2) windows; output grid frames x To x Ho x Wo, input grid frames x (To * pt) x Hi x Wi
+extern "C" int dvd_pool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int Hi, int Wi, int ld, int pt,
                         float scale, void* stream) {
     if (!x || !y || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || (pt != 1 && pt != 2)) return DVD_E_ARG;
-    if (ld & 7) return DVD_E_SHAPE;
+    if ((ld & 7) || Hi / 2 != Ho || Wi / 2 != Wo) return DVD_E_SHAPE;
     const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
-    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale, (const T*)nullptr));
+    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, Hi, Wi, ld, pt, scale,
+                                                                 (const T*)nullptr));
     return launch_status();
 }
 // the same with a ReLU mask on the OUTPUT grid (same layout and leading dimension as y): y = mask > 0 ? pooled : 0
@@ -578,7 +587,8 @@ extern "C" int dvd_pool_masked(int dtype, const void* x, const void* mask, void*
     if (!x || !y || !mask || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || (pt != 1 && pt != 2)) return DVD_E_ARG;
     if (ld & 7) return DVD_E_SHAPE;
     const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
-    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale, (const T*)mask));
+    BY_DTYPE(dtype, pool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, 2 * Ho, 2 * Wo, ld, pt, scale,
+                                                                 (const T*)mask));
     return launch_status();
 }
 // 2x2x2 max pooling; output grid frames x To x Ho x Wo (input 2To x 2Ho x 2Wo)
@@ -598,11 +608,12 @@ extern "C" int dvd_maxpool3d_backward(int dtype, const void* x, const void* dy, 
                                                                           Wo, ld));
     return launch_status();
 }
-// y[t][y][x] = scale * x[t/pt][y/2][x/2]; output grid frames x To x Ho x Wo
+// y[t][y][x] = scale * x[t/pt][y/2][x/2]; output grid frames x To x Ho x Wo (input grid To / pt x Ho / 2 x Wo / 2, floor: the
+// odd line / column of the output is zero -- the transpose of dvd_pool on an odd grid)
 extern "C" int dvd_unpool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt,
                           float scale, void* stream) {
     if (!x || !y || frames <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || (pt != 1 && pt != 2)) return DVD_E_ARG;
-    if ((ld & 7) || (Ho & 1) || (Wo & 1) || (To % pt)) return DVD_E_SHAPE;
+    if ((ld & 7) || (To % pt) || Ho < 2 || Wo < 2) return DVD_E_SHAPE;
     const long long nout = frames * To * Ho * Wo, n = nout * (ld / 8);
     BY_DTYPE(dtype, unpool_kernel<T><<<cdiv(n, 256), 256, 0, S_>>>((const T*)x, (T*)y, nout, To, Ho, Wo, ld, pt, scale));
     return launch_status();

@@ -29,45 +29,40 @@ def load_value_file(path):                      # utils.py:54-58
 
 
 def make_dataset(root_path, annotation_path, subset, n_samples_for_each_video=1, sample_duration=16):
-    """Dataloader/datasets/ucf101.py:82-140: one record per video (or per window) with its frame indices and class index."""
+    """Index of the clips to draw from: one record per video of `subset`, or per `sample_duration`-frame window when
+    n_samples_for_each_video > 1 -- the records Dataloader/datasets/ucf101.py:82-140 builds (same order, same keys), so a
+    seeded run picks the same videos as the reference.  -> (records, {class index: class name})."""
     with open(annotation_path, "r") as f:
         ann = json.load(f)
-    class_to_idx = {name: i for i, name in enumerate(ann["labels"])}
-    names, labels = [], []
-    for key, value in ann["database"].items():
-        if value["subset"] == subset:
-            names.append("{}/{}".format(value["annotations"]["label"], key))
-            labels.append(value["annotations"]["label"])
-    dataset = []
-    for name, label in zip(names, labels):
-        video_path = os.path.join(root_path, name)
-        if not os.path.exists(video_path):
+    index_of = {label: n for n, label in enumerate(ann["labels"])}
+    records = []
+    for vid, entry in ann["database"].items():                 # file order = the reference's order
+        cls = entry["annotations"]["label"]
+        folder = os.path.join(root_path, cls, vid)
+        if entry["subset"] != subset or not os.path.exists(folder) or cls not in index_of:
             continue
-        n_frames = int(load_value_file(os.path.join(video_path, "n_frames")))
-        if n_frames <= 0 or label not in class_to_idx:
+        total = int(load_value_file(os.path.join(folder, "n_frames")))
+        if total <= 0:
             continue
-        sample = {"video": video_path, "segment": [1, n_frames], "n_frames": n_frames, "video_id": name.split("/")[1],
-                  "label": class_to_idx[label]}
         if n_samples_for_each_video == 1:
-            dataset.append(dict(sample, frame_indices=list(range(1, n_frames + 1))))
-        else:
-            step = (max(1, math.ceil((n_frames - 1 - sample_duration) / (n_samples_for_each_video - 1)))
-                    if n_samples_for_each_video > 1 else sample_duration)
-            for j in range(1, n_frames, step):
-                dataset.append(dict(sample, frame_indices=list(range(j, min(n_frames + 1, j + sample_duration)))))
-    return dataset, {i: n for n, i in class_to_idx.items()}
+            windows = [(1, total + 1)]
+        else:                                                   # windows spread evenly over the video, at least one frame apart
+            stride = max(1, math.ceil((total - 1 - sample_duration) / (n_samples_for_each_video - 1)))
+            windows = [(first, min(total + 1, first + sample_duration)) for first in range(1, total, stride)]
+        for lo, hi in windows:
+            records.append({"video": folder, "segment": [1, total], "n_frames": total, "video_id": vid,
+                            "label": index_of[cls], "frame_indices": list(range(lo, hi))})
+    return records, {n: label for label, n in index_of.items()}
 
 
 def temporal_random_crop(frame_indices, size):
-    """Dataloader/transform/temporal_transforms.py:80-110 (loops the clip when it is shorter than `size`)."""
-    rand_end = max(0, len(frame_indices) - size - 1)
-    begin = random.randint(0, rand_end)
-    out = frame_indices[begin:min(begin + size, len(frame_indices))]
-    for index in out:
-        if len(out) >= size:
-            break
-        out.append(index)
-    return out
+    """`size` consecutive frames from a random start; a shorter clip is repeated cyclically up to `size`
+    (Dataloader/transform/temporal_transforms.py:80-110; ONE random.randint draw, like the reference)."""
+    first = random.randint(0, max(0, len(frame_indices) - size - 1))
+    window = frame_indices[first:first + size]
+    if not window or len(window) >= size:
+        return list(window)
+    return [window[i % len(window)] for i in range(size)]
 
 
 class MultiScaleCrop:

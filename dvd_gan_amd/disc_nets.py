@@ -115,8 +115,12 @@ class _SNHolder(nn.Module):
 
 
 def _check_frame_size(H, W):
-    if H < 1 or W < 1 or H & (H - 1) or W & (W - 1):
-        raise ValueError(f"{H}x{W} frames: the HIP convolution kernels need power-of-two frame sizes (64x64, 128x128, ...)")
+    """Any even frame size runs (Discriminators.py:242-291, 400-447 take what their poolings leave): power-of-two extents
+    through the LDS-staged kernels, any other extent (96 x 96, 80 x 80, ...) through the tap-by-tap kernels with division
+    indexing; maps that become odd further down (3 x 3 -> 1 x 1) are floored by the pooling like F.avg_pool2d.  An odd INPUT
+    frame would lose a line in the very first pooling -- the reference floors silently, here it is an error."""
+    if H < 2 or W < 2 or (H | W) & 1:
+        raise ValueError(f"{H}x{W} frames: the discriminators need even frame sizes")
 
 
 class _DiscBase(nn.Module):

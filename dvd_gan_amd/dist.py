@@ -38,12 +38,39 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        backend = backend or ("nccl" if use_cuda else "gloo")
+        kw = {}
+        if backend == "nccl" and os.environ.get("DVD_EXCHANGE_PRIO", "1") != "0":
+            # RCCL's kernels run on ProcessGroupNCCL's OWN internal stream, whatever stream the collective was issued from
+            # (the issuing stream is only fenced with events): that stream is high-priority only when the group is created
+            # with this option.  Without it the all-reduce kernels queue behind the step's launches (two workgroups on every
+            # CU, back to back) at every kernel boundary.
+            opts = nccl_high_priority_options()
+            if opts is not None:
+                kw["pg_options"] = opts
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, (torch.device("cuda", local) if use_cuda else torch.device("cpu"))
+
+
+def nccl_high_priority_options():
+    """ProcessGroupNCCL.Options(is_high_priority_stream=True), or None when this torch build has no nccl backend."""
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except (AttributeError, RuntimeError):
+        return None
 
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def collective_device():
+    """Device a tensor must live on to take part in a collective of the default group."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def _avg_(t):
@@ -69,9 +96,10 @@ class GradExchange:
         self.world = world_size()
         self.stream = None
         if self.world > 1 and torch.cuda.is_available():
-            # The exchange runs on the most urgent priority level: RCCL's all-reduce kernels need a few CUs' worth of
-            # workgroup slots, and the step's own launches (two workgroups on every CU, back to back) would otherwise be
-            # dispatched ahead of them at every kernel boundary.  DVD_EXCHANGE_PRIO=0 puts it on a default-priority stream.
+            # The exchange is ISSUED from a stream of the most urgent priority level; that only orders the event fences around
+            # the collective.  The all-reduce kernels themselves run on ProcessGroupNCCL's internal stream, which
+            # init_from_env creates high-priority (pg_options, is_high_priority_stream) so that they are dispatched at the next
+            # kernel boundary instead of behind the step's queued launches.  DVD_EXCHANGE_PRIO=0 switches both off.
             # (No multi-GPU hardware was available to this build: the setting is by construction, not by measurement.)
             hi = torch.cuda.Stream.priority_range()[1] if os.environ.get("DVD_EXCHANGE_PRIO", "1") != "0" else 0
             self.stream = torch.cuda.Stream(priority=hi)

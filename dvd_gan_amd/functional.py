@@ -28,17 +28,13 @@ from . import lib as L
 # early where a gradient bucket is handed to the exchange.  Parameters without a persistent .grad (stock optimizers with
 # zero_grad(set_to_none=True), module tests) take the autograd route unchanged.
 import os as _os
-_SIDE = {"on": False, "stream": None, "serial": _os.environ.get("DVD_SIDE_SERIAL") == "1",      # env: profiling aid, see below
-         "cb": False,                                                                           # join callback queued for the running backward
-         "defer": False, "queue": [],                                                           # held-back weight-gradient launches
-         "defer_hw": int(_os.environ.get("DVD_DEFER_HW", "16")),
-         "budget": float(_os.environ.get("DVD_DEFER_TF", "0")) * 1e12, "held": 0.0}                                # frame extent from which the time loops release them
+_SIDE = {"on": False, "stream": None,
+         "serial": _os.environ.get("DVD_SIDE_SERIAL") == "1"}      # env: profiling aid (rocprofv3 runs), see serialize_weight_grads
 
 
 def direct_weight_grads(flag):
     """Switch the side-stream / direct-accumulation route on or off (Trainer turns it on; DVD_SIDE_WGRAD=0 vetoes)."""
-    import os
-    _SIDE["on"] = bool(flag) and os.environ.get("DVD_SIDE_WGRAD", "1") != "0"
+    _SIDE["on"] = bool(flag) and _os.environ.get("DVD_SIDE_WGRAD", "1") != "0"
 
 
 def serialize_weight_grads(flag):
@@ -47,103 +43,36 @@ def serialize_weight_grads(flag):
     _SIDE["serial"] = bool(flag)
 
 
-def _cu_mask(n_cus, pattern, total=256):
-    """Mask words selecting n_cus of `total` compute units.  pattern 0: CUs [0, n); 1: evenly spread (every total/n-th);
-    2: half of the chip such that every XCD keeps half of its CUs whether mask bits run XCD-interleaved or XCD by XCD."""
-    words = [0] * ((total + 31) // 32)
-    for i in range(total):
-        if pattern == 0:
-            on = i < n_cus
-        elif pattern == 1:
-            on = (i * n_cus) // total != ((i + 1) * n_cus) // total
-        else:
-            on = ((i >> 3) ^ i ^ (i >> 5)) & 1 == 1
-        if on:
-            words[i // 32] |= 1 << (i % 32)
-    return words
-
-
 def side_stream():
     if _SIDE["stream"] is None:
-        n_cus = int(_os.environ.get("DVD_SIDE_CUS", "0"))
-        if n_cus > 0:         # experiment: the weight-gradient stream on a subset of the CUs (see DESIGN.md section 4, round 3)
-            import ctypes as C
-            from .lib import lib
-            words = _cu_mask(n_cus, int(_os.environ.get("DVD_SIDE_CUPAT", "0")))
-            arr = (C.c_uint * len(words))(*words)
-            out = C.c_void_p()
-            rc = lib().dvd_stream_create_cumask(arr, len(words), C.byref(out))
-            if rc != 0:
-                raise RuntimeError("dvd_stream_create_cumask failed (%d)" % rc)
-            _SIDE["stream"] = torch.cuda.ExternalStream(out.value)
-            return _SIDE["stream"]
-        lo, hi = 0, 0
+        lo = 0
         try:
-            lo, hi = torch.cuda.Stream.priority_range()          # (least, greatest) priority; smaller = more urgent
+            lo = torch.cuda.Stream.priority_range()[0]           # (least, greatest) priority; smaller = more urgent
         except Exception:
             pass
         _SIDE["stream"] = torch.cuda.Stream(priority=lo)
     return _SIDE["stream"]
 
 
-def defer_weight_grads(flag):
-    """While on, the side-stream weight-gradient launches of a backward pass are HELD BACK (in launch order) until the pass
-    reaches a ConvGRU layer whose frames are DVD_DEFER_HW (16) pixels wide or less -- or until the join.  Those time loops are
-    chains of launches too small to fill the chip; beside the large convolutions that come first in a backward pass the weight
-    gradients only time-share the CUs.  OFF unless DVD_SIDE_DEFER=1: measured 537.9-543.0 ms per step against 535.9-536.0 without
-    (round 3, tools/ab_defer.sh) -- the released kernels take every CU and the time loop waits for them."""
-    _SIDE["defer"] = bool(flag) and _os.environ.get("DVD_SIDE_DEFER", "0") == "1"
-    _SIDE["held"] = 0.0
-    if not _SIDE["defer"]:
-        flush_deferred()
-
-
-def flush_deferred():
-    """Launch the held-back weight-gradient work now (on the side stream, ordered after the current stream's queue)."""
-    q = _SIDE["queue"]
-    if not q:
-        return
-    _SIDE["queue"] = []
-    with _on_side(*[t for _, ts in q for t in ts]):
-        for fn, _ in q:
-            fn()
-
-
-def _side_run(fn, *tensors, cost=None):
-    """fn() launches weight-gradient kernels: on the side stream now, or later (see defer_weight_grads).  cost: FLOPs of the
-    launches; with a budget (DVD_DEFER_TF, TFLOP) only that much work is held back per backward pass, the rest goes out at once."""
-    hold = _SIDE["defer"] and not _SIDE["serial"]
-    if hold and _SIDE["budget"] > 0:
-        hold = cost is not None and _SIDE["held"] + cost <= _SIDE["budget"]
-        if hold:
-            _SIDE["held"] += cost
-    if hold:
-        _queue_join()
-        _SIDE["queue"].append((fn, [t for t in tensors if t is not None]))
-        return
+def _side_run(fn, *tensors):
+    """fn() launches weight-gradient kernels: on the side stream, ordered after the current stream's queue."""
     with _on_side(*tensors):
         fn()
 
 
 def join_side():
-    """The current stream waits for everything queued on the weight-gradient stream."""
-    flush_deferred()
+    """The current stream waits for everything queued on the weight-gradient stream (idempotent, one event wait)."""
     if _SIDE["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
 
 
-def _join_after_backward():
-    _SIDE["cb"] = False
-    join_side()
-
-
 def _queue_join():
-    """Called from inside a backward pass: make the running backward() end with join_side()."""
-    if _SIDE["cb"]:
-        return
+    """Called from inside a backward pass: make the running backward() end with join_side().  The callback is queued on EVERY
+    side-stream launch -- the engine runs final callbacks once per backward() and DROPS them when a backward raises, so a
+    process-wide "already queued" flag would survive a failed backward (an OOM that is caught and retried, a user hook error)
+    and silently disable the join for the rest of the process; join_side() is idempotent and costs one event wait."""
     try:
-        torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
-        _SIDE["cb"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_side)
     except RuntimeError:          # not inside a backward pass (a Function.backward driven by hand): the caller joins
         pass
 
@@ -293,7 +222,7 @@ class Conv(Function):
                     K.sn_backward(G, w, u, v, sigma, out=wp.grad)
                 else:
                     K.conv_wgrad(x, dy, wp.grad, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp)
-            _side_run(wgrad, x, dy, w, sigma, cost=2.0 * dy.numel() / dy.shape[-1] * spec.cout * spec.cin * w[0, 0].numel())
+            _side_run(wgrad, x, dy, w, sigma)
         elif ctx.needs_input_grad[1]:
             G = torch.zeros_like(w)
             if ctx.needs_input_grad[2]:           # bias gradient rides along in the wgrad kernel
@@ -317,12 +246,12 @@ class Pool(Function):
 
     @staticmethod
     def forward(ctx, x, pt):
-        ctx.pt = pt
+        ctx.pt, ctx.hw = pt, (x.shape[-3], x.shape[-2])
         return K.pool(x, pt)
 
     @staticmethod
     def backward(ctx, g):
-        return K.unpool(g.contiguous(), ctx.pt), None
+        return K.unpool(g.contiguous(), ctx.pt, out_hw=ctx.hw), None
 
 
 # ------------------------------------------------------------------ fp32 linear / embedding
@@ -442,8 +371,6 @@ class ConvGRULayer(Function):
         T, B, S1, S2, hid, cin, k, shared_x, ws_n = ctx.meta
         dev, dtype = x.device, x.dtype
         M = B * S1 * S2
-        if max(S1, S2) <= _SIDE["defer_hw"]:
-            flush_deferred()          # this time loop leaves CUs idle: the held-back weight gradients run beside it
         dh = dh.contiguous()
         dg = torch.empty(T * B, S1, S2, 3 * hid, dtype=dtype, device=dev)
         carry = torch.empty(M, hid, dtype=torch.float32, device=dev)

@@ -245,18 +245,22 @@ def pool(x, pt=1, scale=None, mask=None):
     shape = (F_, To, Ho, Wo, x.shape[-1]) if x.dim() == 5 else (F_, Ho, Wo, x.shape[-1])
     y = torch.empty(shape, dtype=x.dtype, device=x.device)
     if mask is not None:
-        assert mask.shape == y.shape and mask.dtype == y.dtype
+        assert mask.shape == y.shape and mask.dtype == y.dtype and not ((H | W) & 1)
         L.check(L.lib().dvd_pool_masked(L.dt(x), L.ptr(x), L.ptr(mask), L.ptr(y), _ll(F_), To, Ho, Wo, x.shape[-1], pt, _f(scale),
                                         L.stream()))
         return y
-    L.check(L.lib().dvd_pool(L.dt(x), L.ptr(x), L.ptr(y), _ll(F_), To, Ho, Wo, x.shape[-1], pt, _f(scale), L.stream()))
+    L.check(L.lib().dvd_pool(L.dt(x), L.ptr(x), L.ptr(y), _ll(F_), To, Ho, Wo, H, W, x.shape[-1], pt, _f(scale), L.stream()))
     return y
 
 
-def unpool(x, pt=1, scale=None):
-    """nearest replication to (T*pt, 2H, 2W) times scale (default 1/(4*pt): gradient of avg-pool)."""
+def unpool(x, pt=1, scale=None, out_hw=None):
+    """nearest replication to (T*pt, 2H, 2W) times scale (default 1/(4*pt): gradient of avg-pool).  out_hw = (2H+1 | 2H, 2W+1 |
+    2W): the grid a floored pooling started from -- its odd last line / column gets zeros."""
     F_, T, H, W = _grid4(x)
     To, Ho, Wo = T * pt, H * 2, W * 2
+    if out_hw is not None:
+        Ho, Wo = out_hw
+        assert Ho // 2 == H and Wo // 2 == W
     scale = (1.0 / (4 * pt)) if scale is None else scale
     shape = (F_, To, Ho, Wo, x.shape[-1]) if x.dim() == 5 else (F_, Ho, Wo, x.shape[-1])
     y = torch.empty(shape, dtype=x.dtype, device=x.device)

@@ -47,7 +47,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 BN_NREP = 16            # DVD_BN_NREP of include/dvdgan_hip.h
 
 

@@ -64,8 +64,10 @@ class _PlateauLR:
             raise TypeError("step() missing 1 required positional argument: 'metrics'")
         if D.world_size() > 1:
             # data parallel: every rank must take the SAME lr decision or the replicas' parameters drift apart for good
-            # (only gradients are exchanged) -- the schedulers see the mean of the ranks' losses
-            metric = metric.detach().clone()
+            # (only gradients are exchanged) -- the schedulers see the mean of the ranks' losses.  (A Python float is accepted
+            # like in the single-process path; every rank must call step() every iteration: it is a collective.)
+            dev = metric.device if isinstance(metric, torch.Tensor) else D.collective_device()
+            metric = torch.as_tensor(metric, dtype=torch.float32).detach().to(dev).clone().reshape(1)
             torch.distributed.all_reduce(metric, op=torch.distributed.ReduceOp.SUM)
             metric = metric / D.world_size()
         m = float(metric)
@@ -130,11 +132,18 @@ class Trainer(object):
         # from a generator all ranks seed alike, z / labels from each rank's own default generator
         self._sync_replicas()
         self.frame_gen = torch.Generator().manual_seed(D.shared_seed()) if self.exchange.world > 1 else None
-        # ... and z / z_class of rank r from a generator seeded with (config.seed, r): distinct noise per replica whatever
-        # the caller did to the default generator (equal seeds on all ranks would train every replica on the same draws).
+        # ... and z / z_class of rank r from a generator of its own: distinct noise per replica even when every rank was
+        # seeded alike (equal seeds on all ranks would train every replica on the same draws).  Its seed mixes the rank with
+        # config.seed when the configuration has one, else with a value DRAWN from the caller's default generator -- so
+        # torch.manual_seed(...) before constructing the Trainer steers it, two runs with different seeds draw different
+        # noise, and a resumed run (which re-seeds or not as the caller likes) does not replay a fixed stream.
         # A single process keeps the default generator -- the reference's behaviour (trainer.py:84-88, 236-240).
-        self.noise_gen = (torch.Generator().manual_seed(int(getattr(c, "seed", 0)) * 1000003 + 7919 * self.rank + 1)
-                          if self.exchange.world > 1 else None)
+        self.noise_gen = None
+        if self.exchange.world > 1:
+            base = getattr(c, "seed", None)
+            if base is None:
+                base = int(torch.randint(0, 2 ** 31 - 1, (1,)))
+            self.noise_gen = torch.Generator().manual_seed((int(base) * 1000003 + 7919 * self.rank + 1) % (2 ** 63 - 1))
 
     # ---- trainer.py:345-366
     def build_model(self):
@@ -325,12 +334,8 @@ class Trainer(object):
                 ex.start_range("G", self.g_optimizer.grad, lo, self._g_hi)
                 self._g_hi = min(self._g_hi, lo)
             self.G.grad_ready_hook = on_ready
-        # experiment switch (DVD_SIDE_DEFER=1, single GPU): G's weight gradients held back until the backward pass reaches the
-        # small-frame ConvGRU time loops (functional.defer_weight_grads; measured: no gain)
-        Fn.defer_weight_grads(ex.world == 1)
         (g_s_loss + g_t_loss).backward()
         Fn.join_side()
-        Fn.defer_weight_grads(False)
         if ex.world > 1:
             self.G.grad_ready_hook = None
             ex.start_range("G", self.g_optimizer.grad, 0, self._g_hi)
@@ -340,18 +345,29 @@ class Trainer(object):
         return ds_loss_real, ds_loss_fake, dt_loss_real, dt_loss_fake, g_s_loss, g_t_loss
 
     # ---- trainer.py:189-343 (loop; logging reduced to a print, no sampling)
+    def _new_epoch(self):
+        """-> iterator over the loader for the next epoch.  A rank-sharded loader (data.make_loader: DistributedSampler) shuffles
+        with seed + epoch: without set_epoch every epoch would repeat the same order and the same rank split."""
+        if hasattr(self.data_loader, "set_epoch"):
+            self.data_loader.set_epoch(self._epoch)
+        elif hasattr(getattr(self.data_loader, "sampler", None), "set_epoch"):
+            self.data_loader.sampler.set_epoch(self._epoch)
+        self._epoch += 1
+        return iter(self.data_loader)
+
     def train(self):
-        data_iter = iter(self.data_loader)
         steps_per_epoch = len(self.data_loader)
         total_step = self.total_epoch * steps_per_epoch
         start = (self.pretrained_model + 1) if self.pretrained_model else 1
+        self._epoch = (start - 1) // max(1, steps_per_epoch)       # a resumed run continues with the epoch it stopped in
+        data_iter = self._new_epoch()
         self.D_s.train(); self.D_t.train(); self.G.train()
         t0 = time.time()
         for step in range(start, total_step + 1):
             try:
                 real_videos, real_labels = next(data_iter)
             except StopIteration:
-                data_iter = iter(self.data_loader)
+                data_iter = self._new_epoch()
                 real_videos, real_labels = next(data_iter)
             losses = self.train_step(real_videos, real_labels)
             if self.log_epoch and step % (self.log_epoch * steps_per_epoch) == 0:

@@ -46,11 +46,6 @@ long long dvd_prof_report(int kind, double* total_ms, double* total_flops);
  * 5 = conv_igemm 256x128, 6 = conv_igemm 256x256; kind 1: 1 = filter-row kernel, 2 = one-tap kernel. */
 long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops);
 const char* dvd_strerror(int code);
-/* A HIP stream restricted to a set of compute units (bit i of the nwords 32-bit mask words = CU i), for work that should
- * fill the chip beside a latency-bound chain of small launches without taking every CU from it (the weight-gradient stream of
- * dvd_gan_amd/functional.py); *stream receives a hipStream_t.  dvd_stream_destroy releases it. */
-int dvd_stream_create_cumask(const unsigned* mask, int nwords, void** stream);
-int dvd_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution, stride 1, "same" zero padding, 1-D/2-D/3-D taps (kt,kh,kw odd).
@@ -209,8 +204,10 @@ int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, const void* 
 
 /* avg / sum pooling over (pt,2,2) windows and its transpose (nearest replication), channels-last.
  * F.avg_pool2d / F.avg_pool3d at Discriminators.py:197,206,225,249,352,361,380,408 and the
- * gradient of F.interpolate(scale_factor=2) (GResBlock.py:55,72). Output grid given. */
-int dvd_pool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt, float scale, void* stream);
+ * gradient of F.interpolate(scale_factor=2) (GResBlock.py:55,72). Output grid given; dvd_unpool writes zeros to the last
+ * line / column of an odd output grid (the transpose of a floored pooling). */
+int dvd_pool(int dtype, const void* x, void* y, long long frames, int To, int Ho, int Wo, int Hi, int Wi /* input grid: Hi/2 = Ho,
+             Wi/2 = Wo; an odd extent loses its last line like F.avg_pool2d */, int ld, int pt, float scale, void* stream);
 /* ... followed by a ReLU mask on the output grid (mask: same layout as y): the backward of relu -> nearest x2 -> conv
  * (GResBlock.py:52-57) in one pass instead of a pooling pass plus a masking pass */
 int dvd_pool_masked(int dtype, const void* x, const void* mask, void* y, long long frames, int To, int Ho, int Wo, int ld, int pt,

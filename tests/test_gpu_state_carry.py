@@ -5,8 +5,11 @@ against golden F15 = two steps of the reference Trainer driven the same way (tes
   exact mode (f32 MFMA): six losses (2e-3 relative at step 0), |grad| checksums of every parameter of the three networks at
       their step-0 updates (1e-2), the named gradients and the gradients wrt the twelve supplied states (rel-L2 1e-2), SN u / v
       and BN statistics after two steps.
-  bf16 mode (the timed mode): losses within 2e-2 / 5e-2 absolute (the bounds of the F9 bf16 run: ch=2, weights not
-      bf16-representable, lr 40x the reference's), state gradients and discriminator gradients by cosine.
+  bf16 mode (the timed mode): the same two steps at the REFERENCE's learning rate (5e-5; F15 was recorded at 40x that so that
+      the exact mode's second step is a sensitive check -- at 2e-3 Adam's sign-like first update turns bf16 noise on near-zero
+      gradient elements into whole +-lr weight changes) against the CPU oracle run on the same state / draws at that rate --
+      the oracle whose lr-2e-3 run is pinned on F15 by tests/test_oracle_golden.py: six losses within 2e-2 absolute at both
+      steps, discriminator gradients, named generator gradients and the twelve state gradients by cosine.
 Measured values go to gpurun_out/state_carry_numbers.json when that directory exists.
 """
 import argparse
@@ -43,10 +46,10 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def make_trainer(g, dtype):
+def make_trainer(g, dtype, lr=None):
     from dvd_gan_amd.train_step import Trainer
     ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
-    lr = float(g["meta.lr"])
+    lr = float(g["meta.lr"]) if lr is None else lr
     cfg = argparse.Namespace(adv_loss="hinge", z_dim=z_dim, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
                              total_epoch=1, d_iters=1, batch_size=B, g_lr=lr, d_lr=lr, beta1=0.0, beta2=0.9,
                              n_class=n_class, k_sample=k)
@@ -57,9 +60,9 @@ def make_trainer(g, dtype):
     return tr, steps
 
 
-def run(g, dtype):
+def run(g, dtype, lr=None):
     """-> per step: losses, parameter gradients at each optimizer step, gradients of the supplied states"""
-    tr, steps = make_trainer(g, dtype)
+    tr, steps = make_trainer(g, dtype, lr)
     hidden = [[torch.as_tensor(h).to(DEV).requires_grad_(True) for h in hs] for hs in fixture_hidden(g)]
     snaps = {}
     for tag, net, opt in (("Ds", tr.D_s, tr.ds_optimizer), ("Dt", tr.D_t, tr.dt_optimizer), ("G", tr.G, tr.g_optimizer)):
@@ -128,33 +131,62 @@ def test_state_carry_step_exact_matches_reference(golden):
     _dump()
 
 
+def oracle_steps(g, lr):
+    """The CPU oracle on F15's state, clips, draws and supplied states at learning rate `lr`: per step (losses, gradients at the
+    three optimizer steps, state gradients)."""
+    from oracle import dvdgan_cpu as O
+    ch, T, k, B, n_class, steps, z_dim = [int(v) for v in g["meta.cfg"]]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sds = full_states(g)
+    st = O.TrainState(O.make_state(sds[0]), O.make_state(sds[1]), O.make_state(sds[2]), ch=ch, n_frames=T, k_sample=k,
+                      n_class=n_class, z_dim=z_dim, latent_dim=latent_dim_of(g), adv="hinge", g_lr=lr, d_lr=lr)
+    hidden = [[torch.as_tensor(h).requires_grad_(True) for h in hs] for hs in fixture_hidden(g)]
+    snaps = O.snapshot_grads(st)
+    out = []
+    t = torch.as_tensor
+    for s in range(steps):
+        losses = O.train_step(st, t(fixture_real(g, s)), t(g[f"in.labels.{s}"]), t(g[f"in.z.{s}"]), t(g[f"in.z_class.{s}"]),
+                              g[f"in.perm_real.{s}"], g[f"in.perm_fake.{s}"], hidden=hidden)
+        hg = [[h.grad.detach().clone() for h in hs] for hs in hidden]
+        for hs in hidden:
+            for h in hs:
+                h.grad = None
+        out.append((losses, {tg: {kk: v.clone() for kk, v in d.items()} for tg, d in snaps.items()}, hg))
+    return out
+
+
 def test_state_carry_step_bf16(golden):
     g = golden("f15_state_carry")
-    tr, out = run(g, torch.bfloat16)
-    for s, (losses, snaps, hg) in enumerate(out):
-        want = g[f"out.losses.{s}"]
-        NUMBERS[f"bf16.losses.{s}"] = [losses, [float(v) for v in want]]
-        np.testing.assert_allclose(losses, want, atol=2e-2 if s == 0 else 5e-2, err_msg=f"losses step {s}")
-    losses, snaps, hg = out[0]
+    lr = 5e-5
+    want = oracle_steps(g, lr)
+    np.testing.assert_allclose(want[0][0][:4], g["out.losses.0"][:4], rtol=2e-4, atol=2e-5)   # (the D losses of step 0 do not depend on lr)
+    tr, out = run(g, torch.bfloat16, lr)
     num = {}
-    for tag, bound in (("Ds", 0.999), ("Dt", 0.999)):
-        # the discriminators' own update: all stored gradient heads as one vector
-        a = torch.cat([snaps[tag][kk].reshape(-1)[:v.size].double().cpu() for kk, v in sub(g, f"grad.0.{tag}").items()])
-        b = torch.cat([torch.as_tensor(v).double().reshape(-1) for kk, v in sub(g, f"grad.0.{tag}").items()])
-        num[tag] = cosine(a, b)
-        assert num[tag] >= bound, (tag, num[tag])
-    for gi, hs in enumerate(hg):
-        for l, h in enumerate(hs):
-            v = g[f"hgrad.0.{gi}.{l}"]
-            num[f"dh0.{gi}.{l}"] = cosine(h.reshape(-1)[:v.size], v)
-    for kk, v in sub(g, "grad.0.G").items():
-        num["G." + kk] = cosine(snaps["G"][kk].reshape(-1)[:v.size], v)
-    NUMBERS["bf16.cosines"] = num
+    for s, ((losses, snaps, hg), (wl, wsn, whg)) in enumerate(zip(out, want)):
+        NUMBERS[f"bf16.losses.{s}"] = [losses, [float(v) for v in wl]]
+        num[f"loss_err.{s}"] = float(np.abs(np.array(losses) - np.array(wl)).max())
+        for tag in ("Ds", "Dt", "G"):
+            a = torch.cat([snaps[tag][kk].reshape(-1).double().cpu() for kk in sorted(wsn[tag])])
+            b = torch.cat([wsn[tag][kk].reshape(-1).double() for kk in sorted(wsn[tag])])
+            num[f"cos.{s}.{tag}"] = cosine(a, b)
+        for gi, hs in enumerate(hg):
+            for l, h in enumerate(hs):
+                num[f"cos.{s}.dh0.{gi}.{l}"] = cosine(h, whg[gi][l])
+        for kk in sorted(sub(g, "grad.0.G")):
+            num[f"cos.{s}.G.{kk}"] = cosine(snaps["G"][kk], wsn["G"][kk])
+    NUMBERS["bf16"] = num
     _dump()
+    for s in range(len(out)):
+        assert num[f"loss_err.{s}"] <= 2e-2, (s, num[f"loss_err.{s}"])
+        assert num[f"cos.{s}.Ds"] >= 0.999 and num[f"cos.{s}.Dt"] >= 0.999, (s, num[f"cos.{s}.Ds"], num[f"cos.{s}.Dt"])
+        assert num[f"cos.{s}.G"] >= 0.99, (s, num[f"cos.{s}.G"])
     # gradients that travel back through the generator: the last ConvGRU's states sit closest to the loss, the first one's
     # behind all four recurrences (cf. DESIGN.md section 2 on the one-ulp sensitivity of the early layers)
     for key, c in num.items():
-        if key.startswith("dh0.3") or key.startswith("G.conv.9") or key.startswith("G.conv.11") or key.startswith("G.colorize"):
+        if not key.startswith("cos.0."):
+            continue
+        kk = key[len("cos.0."):]
+        if kk.startswith(("dh0.3", "G.conv.9", "G.conv.11", "G.colorize")):
             assert c >= 0.99, (key, c)
-        elif key.startswith(("dh0.", "G.")):
+        elif kk.startswith(("dh0.", "G.")):
             assert c >= 0.9, (key, c)

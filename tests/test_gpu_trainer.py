@@ -424,3 +424,70 @@ def test_inference_forward_equals_training_forward_and_keeps_no_bptt_tensors(dty
     y_infer, mem_infer = run(True)
     assert torch.equal(y_train, y_infer)
     assert mem_infer < 0.6 * mem_train, (mem_infer, mem_train)
+
+
+def test_step_at_96x96_frames_matches_oracle():
+    """Frames that are NOT powers of two (latent_dim = 6 -> 96 x 96 clips; Discriminators.py:242-291 / 400-447 take any frame
+    their poolings can halve): one hinge step at ch=2, T=8, k=4, B=2 in exact mode against the CPU oracle.  Generator and both
+    discriminators run the division-indexed tap-by-tap convolution / weight-gradient kernels; D_t's last block pools a 3 x 3 map
+    to 1 x 1 with F.avg_pool2d's floor (odd-grid dvd_pool / dvd_unpool); D_s attention over 576 tokens, D_t over 144."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.train_step import Trainer
+    torch.manual_seed(17)
+    ch, T, k, B, ncls, zd, ld = 2, 8, 4, 2, 3, 16, 6
+    cfg = argparse.Namespace(adv_loss="hinge", z_dim=zd, g_chn=ch, ds_chn=ch, dt_chn=ch, n_frames=T, lr_schr="const",
+                             total_epoch=1, d_iters=1, batch_size=B, g_lr=5e-5, d_lr=5e-5, beta1=0.0, beta2=0.9,
+                             n_class=ncls, k_sample=k)
+    tr = Trainer([], cfg, device=torch.device("cuda", 0), compute_dtype=torch.float32, latent_dim=ld)
+    sds = [O.make_state({kk: v.detach().cpu().clone() for kk, v in net.state_dict().items()})
+           for net in (tr.G, tr.D_s, tr.D_t)]
+    st = O.TrainState(*sds, ch=ch, n_frames=T, k_sample=k, n_class=ncls, z_dim=zd, latent_dim=ld)
+    snaps_o = O.snapshot_grads(st)
+    snaps = {}
+    for tag, net, opt in (("Ds", tr.D_s, tr.ds_optimizer), ("Dt", tr.D_t, tr.dt_optimizer), ("G", tr.G, tr.g_optimizer)):
+        def stepper(net=net, tag=tag, orig=opt.step):
+            snaps[tag] = {kk: p.grad.clone() for kk, p in net.named_parameters() if p.grad is not None}
+            orig()
+        opt.step = stepper
+    real = torch.rand(B, 3, T, 96, 96) * 2 - 1
+    labels = torch.randint(0, ncls, (B,))
+    draws = {"perm_real": torch.randperm(T), "z": torch.randn(B, zd), "z_class": torch.randint(0, ncls, (B,)),
+             "perm_fake": torch.randperm(T)}
+    got = [float(v.detach()) for v in tr.train_step(real, labels, draws)]
+    want = O.train_step(st, real, labels, draws["z"], draws["z_class"], draws["perm_real"], draws["perm_fake"])
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
+    for tag in ("Ds", "Dt", "G"):                 # every parameter gradient of the three updates
+        scale = max(float(v.norm()) for v in snaps_o[tag].values())
+        for kk, v in snaps_o[tag].items():
+            d = float((snaps[tag][kk].double().cpu() - v.double()).norm())
+            assert d < 1e-2 * float(v.norm()) + 1e-5 * scale, (tag, kk, d, float(v.norm()))
+
+
+@pytest.mark.parametrize("size", [80, 72])
+def test_discriminators_on_even_frames_that_floor(size):
+    """80 x 80 (D_s: 5 x 5 -> 2 x 2, D_t: 5 x 5 -> 2 x 2 -> 1 x 1) and 72 x 72 (D_s: 9 x 9 -> 4 x 4): maps that become odd inside the
+    towers are floored by the pooling like F.avg_pool2d; outputs and every parameter / input gradient against the oracle."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd.disc_nets import SpatialDiscriminator, TemporalDiscriminator
+    torch.manual_seed(size)
+    B, T, k, ncls, ch = 2, 8, 3, 3, 2
+    for kind in ("s", "t"):
+        net = (SpatialDiscriminator if kind == "s" else TemporalDiscriminator)(ch, ncls, compute_dtype=torch.float32).to(DEV).train()
+        with torch.no_grad():
+            (net.attn if kind == "s" else net.self_attn).gamma.fill_(0.7)
+        sd = O.make_state({kk: v.detach().cpu().clone() for kk, v in net.state_dict().items()})
+        x = (torch.rand(B, k, 3, size, size) if kind == "s" else torch.rand(B, 3, T, size // 2, size // 2)) * 2 - 1
+        cls = torch.randint(0, ncls, (B,))
+        xo = x.clone().requires_grad_(True)
+        want = (O.spatial_disc if kind == "s" else O.temporal_disc)(sd, xo, cls)
+        gy = torch.randn_like(want)
+        want.backward(gy)
+        xg = x.to(DEV).requires_grad_(True)
+        got = net(xg, cls.to(DEV))
+        got.backward(gy.to(DEV))
+        assert rel_l2(got, want.detach()) < 1e-4, (kind, size)
+        assert rel_l2(xg.grad, xo.grad) < 2e-4, (kind, size)
+        for kk, p in net.named_parameters():
+            if p.grad is not None:
+                v = sd[kk].grad
+                assert float((p.grad.double().cpu() - v.double()).norm()) < 2e-4 * float(v.norm()) + 1e-7, (kind, size, kk)

@@ -117,8 +117,9 @@ def test_argument_validation_messages():
     with pytest.raises(ValueError, match="latent_dim"):
         Generator(120, 0, 4, 2, 4)
     Generator(120, 6, 4, 2, 4)                      # 96 x 96 clips: built (division-indexed kernels), tests/test_gpu_modules.py
-    with pytest.raises(ValueError, match="power-of-two"):
-        _check_frame_size(96, 96)
+    _check_frame_size(96, 96)                       # any even frame size runs (tests/test_gpu_trainer.py, 96 x 96 step)
+    with pytest.raises(ValueError, match="even frame sizes"):
+        _check_frame_size(65, 64)
     with pytest.raises(ValueError, match="ch even"):
         Generator(120, 4, 4, 3, 4)
     tr = Trainer.__new__(Trainer)
@@ -175,3 +176,40 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_trainer_advances_the_sampler_epoch():
+    """a rank-sharded loader (DistributedSampler) shuffles with seed + epoch; Trainer.train must call set_epoch before
+    every pass over the loader -- first pass, wrap-around and resume included -- or every epoch repeats the same order and the
+    same rank split.  Host logic only: the step itself is stubbed out."""
+    import torch
+    import torch.utils.data as tud
+    from dvd_gan_amd.train_step import Trainer
+
+    ds = tud.TensorDataset(torch.arange(12).float().view(12, 1), torch.arange(12))
+    sampler = tud.distributed.DistributedSampler(ds, num_replicas=2, rank=1, shuffle=True, seed=5, drop_last=True)
+    loader = tud.DataLoader(ds, batch_size=2, sampler=sampler, drop_last=True)
+    seen = []
+
+    class Stub(Trainer):
+        def __init__(self, loader, epochs, start=None):          # no models, no device: only what train() reads
+            self.data_loader, self.total_epoch, self.pretrained_model = loader, epochs, start
+            self.log_epoch = self.model_save_epoch = 0
+            self.D_s = self.D_t = self.G = torch.nn.Identity()
+
+        def train_step(self, real_videos, real_labels):
+            seen.append(real_labels.tolist())
+            return ()
+
+    Stub(loader, 3).train()
+    per = len(loader)
+    epochs = [sum(seen[e * per:(e + 1) * per], []) for e in range(3)]
+    assert len({tuple(e) for e in epochs}) == 3, epochs          # three different orders / rank splits
+    want = []
+    for e in range(3):                                           # ... exactly the sampler's own epochs 0, 1, 2
+        sampler.set_epoch(e)
+        want.append([int(ds[i][1]) for i in sampler][:per * 2])
+    assert epochs == want
+    del seen[:]
+    Stub(loader, 3, start=2 * per).train()                       # resumed after two epochs: continues with epoch 2
+    assert sum(seen, []) == want[2]
