@@ -192,28 +192,28 @@ __global__ void gru_dh0_kernel(const float* carry, const float* ws, int ns, floa
 }
 
 // recurrent conv whose epilogue applies the gate math directly (no split-K, no fp32 slabs)
-int conv_fused(int dtype, int B, int H, int W, int k, const void* in, int C, const void* w, int Cout, const GruEpi& g,
+int conv_fused(int dtype, int B, int H, int W, int k, const void* in, int C, const void* w, const void* wq, int Cout, const GruEpi& g,
                void* stream) {
     dvd_conv_desc d = {};
     d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = C; d.Cout = Cout; d.ldo = Cout;
-    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.out = g.mode == 1 ? g.u : g.hn;   // (`out` itself is not written)
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.wq = wq; d.out = g.mode == 1 ? g.u : g.hn;   // (`out` itself is not written)
     return dvd_conv_forward_gru(&d, &g, stream);
 }
 
 // backward-data conv of the BPTT whose epilogue folds the result into the carry / gate gradients (modes 3, 4)
-int conv_fused_bwd(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, int Cout,
+int conv_fused_bwd(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, const void* wq, int Cout,
                    const GruEpi& g, void* stream) {
     dvd_conv_desc d = {};
     d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = ldi; d.Cout = Cout; d.ldo = Cout;
-    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.out = g.h32n;     // `out` itself is not written
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.wq = wq; d.out = g.h32n;     // `out` itself is not written
     return dvd_conv_forward_gru(&d, &g, stream);
 }
 
-int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, int Cout,
+int conv_slabs(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, const void* wq, int Cout,
                int nsplit, float* ws, void* stream) {
     dvd_conv_desc d = {};
     d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = ldi; d.Cout = Cout; d.ldo = Cout;
-    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = nsplit; d.in = in; d.w = w; d.ws = ws;
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = nsplit; d.in = in; d.w = w; d.wq = wq; d.ws = ws;
     return dvd_conv_forward(&d, stream);
 }
 
@@ -281,11 +281,11 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
         g.u = u; g.r = r; g.hr = hr; g.o = o; g.hn = hn; g.h32n = h32n;
         if (hprev && ns_ur == 1) {           // enough output tiles: gates applied in the conv epilogue
             g.mode = 1;
-            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hprev, h, d->w_ur, 2 * h, g, stream);
+            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hprev, h, d->w_ur, d->w_ur_q, 2 * h, g, stream);
             if (rc) return rc;
         } else {
             if (hprev) {
-                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hprev, h, h, d->w_ur, 2 * h, ns_ur, d->ws, stream);
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hprev, h, h, d->w_ur, d->w_ur_q, 2 * h, ns_ur, d->ws, stream);
                 if (rc) return rc;
                 ns = ns_ur;
             }
@@ -295,11 +295,11 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
         ns = 0;
         if (hprev && ns_o == 1) {
             g.mode = 2;
-            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hr, h, d->w_o, h, g, stream);
+            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hr, h, d->w_o, d->w_o_q, h, g, stream);
             if (rc) return rc;
         } else {
             if (hprev) {
-                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hr, h, h, d->w_o, h, ns_o, d->ws, stream);
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, hr, h, h, d->w_o, d->w_o_q, h, ns_o, d->ws, stream);
                 if (rc) return rc;
                 ns = ns_o;
             }
@@ -344,11 +344,11 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
         g.h = h; g.ldg = 3 * h; g.r = const_cast<char*>(r); g.hprev = hprev; g.h32n = d->carry; g.o = dg;
         if (hprev && ns_o == 1) {            // d(h*r) conv applies the reset-gate step in its epilogue
             g.mode = 3;
-            rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, h, g, stream);
+            rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, d->wd_o_q, h, g, stream);
             if (rc) return rc;
         } else {
             if (hprev) {
-                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, h, ns_o, d->ws,
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, d->wd_o_q, h, ns_o, d->ws,
                                 stream);
                 if (rc) return rc;
                 ns = ns_o;
@@ -369,10 +369,10 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
                     g.o = (char*)d->dg + tp * M * 3 * h * esz;
                     out_done = true;
                 }
-                rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, h, g, stream);
+                rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, d->wd_ur_q, h, g, stream);
                 if (rc) return rc;
             } else {
-                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, h, ns_ur, d->ws, stream);
+                rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, d->wd_ur_q, h, ns_ur, d->ws, stream);
                 if (rc) return rc;
                 ns_pending = ns_ur;
             }

@@ -187,7 +187,7 @@ class Conv(Function):
         # its upsample: GResBlock.py:72-73 commute exactly)
         ru = res is not None and res.shape[-2] * 2 == K._grid(x, spec.ksize, spec.up2)[3]
         y = K.conv_forward(x, pk.wf, spec.ksize, spec.cout, bias=b, res=res, act=spec.act, up2=spec.up2,
-                           relu_in=spec.relu_in, res_up2=ru)
+                           relu_in=spec.relu_in, res_up2=ru, wq=lambda: pk.fragment_major("wf"))
         ctx.spec, ctx.pk, ctx.sigma = spec, pk, spec.sigma
         ctx.has_res, ctx.res_up2 = res is not None, ru
         ctx.params = (w, b)                      # the Parameter objects themselves (their .grad buffers)
@@ -204,10 +204,11 @@ class Conv(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if spec.up2:
-                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip)
+                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, wq=lambda: pk.fragment_major("wd"))
                 dx = K.pool(dx, 1, scale=1.0, mask=x if spec.relu_in else None)      # transpose of nearest x2 (+ ReLU mask)
             else:
-                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None)
+                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None,
+                                    wq=lambda: pk.fragment_major("wd"))
         wp, bp = ctx.params
         if ctx.needs_input_grad[1] and _direct(wp, bp if ctx.needs_input_grad[2] else None):
             # side stream, straight into the persistent .grad buffers (see the note at the top of this file)
@@ -331,7 +332,7 @@ class ConvGRULayer(Function):
         pur.fill(wu, co_off=0, ci_off=cin).fill(wr, co_off=hid, ci_off=cin)
         po.fill(wo, ci_off=cin)
         bias3 = torch.cat([bu, br, bo])
-        gx = K.conv_forward(x, px.wf, (k, k), 3 * hid, bias=bias3)
+        gx = K.conv_forward(x, px.wf, (k, k), 3 * hid, bias=bias3, wq=lambda: px.fragment_major("wf"))
         mk = lambda n=T: torch.empty(n, B, S1, S2, hid, dtype=dtype, device=dev)
         if infer:
             h_all, u_all, hr_all, r_all, o_all = mk(), mk(1), mk(1), None, None
@@ -348,6 +349,11 @@ class ConvGRULayer(Function):
         d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.dt(x), T, B, S1, S2, hid, k
         d.gx_stride = 0 if shared_x else M * 3 * hid
         d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
+        # the recurrent convolutions on frames of 16 pixels and more read their weights in fragment-major order
+        if K.wants_fragment_major(dtype, B, S1, S2, hid, 2 * hid, k, ns1):
+            d.w_ur_q = pur.fragment_major("wf").data_ptr()
+        if K.wants_fragment_major(dtype, B, S1, S2, hid, hid, k, ns2):
+            d.w_o_q = po.fragment_major("wf").data_ptr()
         d.h0 = h0.data_ptr() if h0 is not None else None
         d.h_all, d.u_all, d.hr_all = h_all.data_ptr(), u_all.data_ptr(), hr_all.data_ptr()
         d.r_all = r_all.data_ptr() if r_all is not None else None
@@ -378,6 +384,13 @@ class ConvGRULayer(Function):
         d = L.GruDesc()
         d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.dt(x), T, B, S1, S2, hid, k
         d.wd_ur, d.wd_o = pur.wd.data_ptr(), po.wd.data_ptr()
+        lib = L.lib()
+        ns_o = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, hid, k * k)
+        ns_ur = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, 2 * hid, k * k)
+        if K.wants_fragment_major(dtype, B, S1, S2, 2 * hid, hid, k, ns_ur):
+            d.wd_ur_q = pur.fragment_major("wd").data_ptr()
+        if K.wants_fragment_major(dtype, B, S1, S2, hid, hid, k, ns_o):
+            d.wd_o_q = po.fragment_major("wd").data_ptr()
         d.h0 = h0.data_ptr() if h0 is not None else None
         d.h_all, d.u_all, d.r_all = h_all.data_ptr(), u_all.data_ptr(), r_all.data_ptr()
         d.o_all, d.hr_all = o_all.data_ptr(), hr_all.data_ptr()
@@ -389,7 +402,7 @@ class ConvGRULayer(Function):
         L.check(L.lib().dvd_convgru_layer_backward(C.byref(d), L.stream()))
         # ---- everything below is batched over all T steps ----
         dgx = K.sum_leading(dg.view(T, -1)).view(B, S1, S2, 3 * hid) if shared_x else dg
-        dx = K.conv_forward(dgx, px.wd, (k, k), px.cip) if ctx.needs_input_grad[0] else None
+        dx = K.conv_forward(dgx, px.wd, (k, k), px.cip, wq=lambda: px.fragment_major("wd")) if ctx.needs_input_grad[0] else None
         ctot = cin + hid
         hflat = h_all.view(T * B, S1, S2, hid)
         hrflat = hr_all.view(T * B, S1, S2, hid)

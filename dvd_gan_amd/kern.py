@@ -73,6 +73,19 @@ class PackedConv:
         self.wf = af(self.ntaps, cout_tot, self.cip, dtype=dtype, device=device)
         self.wd = ad(self.ntaps, self.cip, self.cop, dtype=dtype, device=device) if need_dgrad else None
 
+    def fragment_major(self, which="wf"):
+        """The forward ("wf") or backward-data ("wd") image once more in fragment-major order (dvd_conv_fragment_major), for
+        the convolution kernel that reads its weight operand straight from L2; built on first use, after the last fill()."""
+        q = getattr(self, which + "q", None)
+        if q is None:
+            src = getattr(self, which)
+            cout, c = (self.cout, self.cip) if which == "wf" else (self.cip, self.cop)
+            n = L.lib().dvd_conv_fragment_major_bytes(self.ntaps, cout, c)
+            q = torch.empty(n // 2, dtype=src.dtype, device=src.device)
+            L.check(L.lib().dvd_conv_fragment_major(L.dt(src), L.ptr(src), L.ptr(q), self.ntaps, cout, c, L.stream()))
+            setattr(self, which + "q", q)
+        return q
+
     def fill(self, w, sigma=None, co_off=0, ci_off=0):
         """w: fp32 master [Cout_part, Cin_tot, *k] of which input channels [ci_off, ci_off+cin) are
         packed as output rows [co_off, co_off+Cout_part); sigma: device scalar tensor or None."""
@@ -85,6 +98,21 @@ class PackedConv:
 
 
 # ------------------------------------------------------------------ convolution
+def wants_fragment_major(dtype, frames, H, W, cin, cout, k, nsplit=1):
+    """True when a [frames, H, W, C] -> cout convolution with k x k taps (nsplit K slices) runs through the kernel that takes a
+    fragment-major weight image (dvd_conv_wants_fragment_major)."""
+    if dtype != torch.bfloat16:
+        return False
+    d = L.ConvDesc()
+    d.dtype, d.frames, d.T, d.H, d.W = L.BF16, frames, 1, H, W
+    d.C, d.ldi, d.Cout, d.ldo = cin, cin, cout, cout
+    d.kt, d.kh, d.kw, d.nsplit = 1, k, k, max(1, nsplit)
+    d.inp = d.out = d.w = 1               # (never dereferenced: geometry query)
+    if nsplit > 1:
+        d.ws = 1
+    return bool(L.lib().dvd_conv_wants_fragment_major(C.byref(d)))
+
+
 def _grid(x, ksize, up2):
     """(frames, T, H, W) of the OUTPUT for input x [F,(T,)H,W,C]."""
     if x.dim() == 5:
@@ -102,7 +130,7 @@ def _grid(x, ksize, up2):
 
 
 def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L.ACT_NONE, up2=False,
-                 relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None, res_up2=False):
+                 relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None, res_up2=False, wq=None):
     """Direct (nsplit=1) or split-K convolution.  `wpack`: [ntaps][cout][Cp] tensor.  Returns the
     output tensor [F,(T,)H,W,cout_pad] (direct) or the fp32 slabs [nsplit, M, cout] (split-K)."""
     k = _ksize3(ksize)
@@ -115,6 +143,12 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
     d.kt, d.kh, d.kw = k
     d.up2, d.relu_in, d.nsplit, d.act, d.out_f32 = int(up2), int(relu_in), nsplit, act, int(out_f32)
     d.inp, d.w, d.bias = x.data_ptr(), wpack.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    if callable(wq):                      # lazily built fragment-major image: only when this request runs through that kernel
+        d.nsplit, d.out = max(1, nsplit), 1          # (placeholders for the geometry query; the real pointers are set below)
+        d.ws = 1 if (nsplit > 1 or slabs or ws is not None) else None
+        wq = wq() if (x.dtype == torch.bfloat16 and L.lib().dvd_conv_wants_fragment_major(C.byref(d))) else None
+    d.wq = wq.data_ptr() if wq is not None else None
+    d.out = d.ws = None
     nk = k[0] * k[1] * k[2] * ((Cp + (31 if x.dtype == torch.bfloat16 else 15)) // (32 if x.dtype == torch.bfloat16 else 16))
     nsplit = d.nsplit = max(1, min(nsplit, nk))
     if nsplit > 1 or slabs or ws is not None:

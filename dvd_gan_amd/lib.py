@@ -18,7 +18,7 @@ class ConvDesc(C.Structure):
                 ("nsplit", C.c_int), ("act", C.c_int), ("out_f32", C.c_int), ("ldres", C.c_int),
                 ("ldmask", C.c_int), ("res_up2", C.c_int),
                 ("inp", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
-                ("mask", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p)]
+                ("mask", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("wq", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -42,6 +42,7 @@ def lib():
         _lib.dvd_strerror.restype = C.c_char_p
         _lib.dvd_conv_wgrad_ws_floats.restype = C.c_longlong
         _lib.dvd_sepattn_work_floats.restype = C.c_longlong
+        _lib.dvd_conv_fragment_major_bytes.restype = C.c_longlong
         if _lib.dvd_abi_version() != ABI_VERSION:
             raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
     return _lib
@@ -83,7 +84,8 @@ class GruDesc(C.Structure):
                 ("h_all", C.c_void_p), ("u_all", C.c_void_p), ("r_all", C.c_void_p), ("o_all", C.c_void_p),
                 ("hr_all", C.c_void_p), ("h32", C.c_void_p), ("ws", C.c_void_p),
                 ("dh_out", C.c_void_p), ("dg", C.c_void_p), ("carry", C.c_void_p), ("dh0", C.c_void_p),
-                ("infer", C.c_int)]
+                ("infer", C.c_int),
+                ("w_ur_q", C.c_void_p), ("w_o_q", C.c_void_p), ("wd_ur_q", C.c_void_p), ("wd_o_q", C.c_void_p)]
 
 
 class SnItem(C.Structure):              # == dvd_sn_item

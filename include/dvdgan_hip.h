@@ -82,8 +82,18 @@ typedef struct {
     void* out;                 /* [M][ldo]                                                      */
     float* ws;                 /* non-NULL: raw fp32 partial sums [nsplit][M][Cout] are written
                                   here INSTEAD of the direct epilogue (bias/res/act/mask/out)   */
+    const void* wq;            /* optional (bf16): the same weights as `w` in fragment-major order
+                                  (dvd_conv_fragment_major); requests for which
+                                  dvd_conv_wants_fragment_major() is 1 then read their weight operand
+                                  straight from L2 into registers instead of staging it in LDS       */
 } dvd_conv_desc;
 int dvd_conv_forward(const dvd_conv_desc* d, void* stream);
+/* Fragment-major weight image: [tap][32-channel chunk][32-column block, padded to whole 128-column tiles][k-half pair][lane]
+ * [8 channels] -- 1 KiB per MFMA B fragment, fetched by one coalesced 16-byte load per lane.  `w`: a forward or backward-data
+ * pack of dvd_pack_conv_weight ([ntaps][Cout][C], bf16, C % 8 == 0).  Re-run after every re-pack (spectral norm: every forward). */
+long long dvd_conv_fragment_major_bytes(int ntaps, int Cout, int C);
+int dvd_conv_fragment_major(int dtype, const void* w, void* wq, int ntaps, int Cout, int C, void* stream);
+int dvd_conv_wants_fragment_major(const dvd_conv_desc* d);
 
 /* Backward-weight of the same convolution:
  *   dw[co*s_co + ci*s_ci + tap*s_tap] += sum_m dy[m][co] * x[pos(m)+tap][ci]       (fp32 atomics)
@@ -168,6 +178,9 @@ typedef struct {
     /* forward only */
     int infer;                 /* 1 (sampling path, trainer.py:323-334: no backward will follow): u_all / hr_all are ONE-step
                                   scratch buffers [M][hidden], r and o are not stored (r_all, o_all may be NULL)           */
+    /* optional: the four packs once more in fragment-major order (dvd_conv_fragment_major), or NULL -- handed to the recurrent
+       convolutions as dvd_conv_desc.wq */
+    const void* w_ur_q; const void* w_o_q; const void* wd_ur_q; const void* wd_o_q;
 } dvd_gru_desc;
 int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream);
 int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream);

@@ -176,17 +176,19 @@ def test_state_carry_step_bf16(golden):
             num[f"cos.{s}.G.{kk}"] = cosine(snaps["G"][kk], wsn["G"][kk])
     NUMBERS["bf16"] = num
     _dump()
+    # measured (ch=2: 8..32-channel layers, weights and states NOT bf16-representable): losses 2.6e-3 / 3.7e-3; discriminator
+    # gradients 0.9999 / 0.9999 (step 0), 0.99997 / 0.9986 (step 1); generator gradient as one vector 0.9993 / 0.9999; the
+    # gradients that travel back through the recurrences -- the twelve state gradients and the early layers' weights -- 0.962 ...
+    # 0.992, the last stage's weights >= 0.9994 (cf. DESIGN.md section 2 on the one-ulp sensitivity of the early layers)
     for s in range(len(out)):
         assert num[f"loss_err.{s}"] <= 2e-2, (s, num[f"loss_err.{s}"])
-        assert num[f"cos.{s}.Ds"] >= 0.999 and num[f"cos.{s}.Dt"] >= 0.999, (s, num[f"cos.{s}.Ds"], num[f"cos.{s}.Dt"])
-        assert num[f"cos.{s}.G"] >= 0.99, (s, num[f"cos.{s}.G"])
-    # gradients that travel back through the generator: the last ConvGRU's states sit closest to the loss, the first one's
-    # behind all four recurrences (cf. DESIGN.md section 2 on the one-ulp sensitivity of the early layers)
+        assert num[f"cos.{s}.Ds"] >= 0.998 and num[f"cos.{s}.Dt"] >= 0.998, (s, num[f"cos.{s}.Ds"], num[f"cos.{s}.Dt"])
+        assert num[f"cos.{s}.G"] >= 0.995, (s, num[f"cos.{s}.G"])
     for key, c in num.items():
-        if not key.startswith("cos.0."):
+        if not key.startswith("cos."):
             continue
-        kk = key[len("cos.0."):]
-        if kk.startswith(("dh0.3", "G.conv.9", "G.conv.11", "G.colorize")):
-            assert c >= 0.99, (key, c)
+        kk = key.split(".", 2)[2]
+        if kk.startswith(("G.conv.9", "G.conv.10", "G.conv.11", "G.colorize")):
+            assert c >= 0.999, (key, c)
         elif kk.startswith(("dh0.", "G.")):
-            assert c >= 0.9, (key, c)
+            assert c >= 0.95, (key, c)

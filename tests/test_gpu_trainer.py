@@ -366,8 +366,10 @@ def test_step_at_reference_default_init(golden, mode):
 def test_bf16_trajectory_follows_exact_mode(golden):
     """20 optimizer steps from the reference's default initialisation (F14 state, ch=4, T=16, B=2, hinge, lr 5e-5) in exact
     mode and in bf16 mode on the same clips and RNG draws: the bf16 trajectory must stay beside the exact one -- every
-    loss term within 1e-2 absolute at every step (measured: 4.1e-3 at worst, no growth over the 20 steps), nothing
-    non-finite, and the parameter displacement of the two runs (both have moved every weight by ~20 Adam steps of 5e-5)
+    loss term within 2e-2 absolute at every step and 4e-3 on average, nothing non-finite (measured over eight runs: worst
+    term 2.9e-3 ... 1.2e-2, mean 1e-3; the runs differ among themselves -- the weight gradients of these 16..32-channel layers go
+    through fp32 atomics, so even two exact-mode runs part in the fourth digit after 20 Adam steps; round 3 quoted 1e-2 from a
+    single run at 4.1e-3 and the bound then failed about one run in four), and the parameter displacement of the two runs (both have moved every weight by ~20 Adam steps of 5e-5)
     agreeing to cosine >= 0.99 for each network (measured 0.9995 / 0.99999 / 0.99999)."""
     import json, os
     g = golden("f14_default_init_bf16")
@@ -394,7 +396,8 @@ def test_bf16_trajectory_follows_exact_mode(golden):
     with open("gpurun_out/f14_trajectory.json", "w") as f:
         json.dump({"max_abs_dev_per_term": dev.max(0).tolist(), "max_abs_dev_per_step": dev.max(1).tolist(),
                    "displacement_cosine_G_Ds_Dt": cos, "exact_losses": he.tolist(), "bf16_losses": hb.tolist()}, f, indent=1)
-    assert dev.max() < 1e-2, dev.max(0)
+    assert dev.max() < 2e-2, dev.max(0)
+    assert dev.mean() < 4e-3, dev.mean(0)
     assert min(cos) > 0.99, cos
 
 

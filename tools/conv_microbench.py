@@ -39,6 +39,9 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (3072, 32, 256, 128, 5, False),
     (3072, 32, 128, 768, 5, False),   # 28: gru3.l1 x-part (short K, wide N)
     (3072, 32, 768, 128, 5, False),   # 29: its backward-data
+    (3072, 64, 64, 64, 3, False),     # 30: thin output (256 x 64 tile): last GResBlock conv1
+    (3072, 64, 128, 64, 3, False),    # 31
+    (512, 64, 64, 64, 3, False),      # 32: D_s pre_conv.2
 ]
 
 
@@ -82,6 +85,20 @@ def main():
             ns = L.lib().dvd_conv_pick_nsplit(L.BF16, C.c_longlong(M), Cout, Cin, k * k) if slabs else 1
             ws = torch.empty(ns, M, Cout, device=dev) if slabs else None
             out = None if slabs else torch.empty(F_, S, S, Cout, device=dev, dtype=dt)
+            if os.environ.get("GB") == "1":        # interleaved A/B: weights through LDS vs straight from L2 (fragment-major image)
+                wq = pk.fragment_major("wf")
+                ref = K.conv_forward(x, pk.wf, (k, k), Cout, nsplit=ns, slabs=slabs)
+                got = K.conv_forward(x, pk.wf, (k, k), Cout, nsplit=ns, slabs=slabs, wq=wq)
+                same = bool(torch.equal(ref, got))
+                res = []
+                for _ in range(3):
+                    a_ = bench(lambda: K.conv_forward(x, pk.wf, (k, k), Cout, nsplit=ns, ws=ws, out=out), iters)
+                    b_ = bench(lambda: K.conv_forward(x, pk.wf, (k, k), Cout, nsplit=ns, ws=ws, out=out, wq=wq), iters)
+                    res.append((a_, b_))
+                a_, b_ = min(r[0] for r in res), min(r[1] for r in res)
+                print(f"fwd   M={M:8d} C={Cin:5d} Cout={Cout:5d} k={k} split={ns:2d}: lds {a_ * 1e3:9.1f} us {fl / a_ / 1e9:7.1f} TF/s | "
+                      f"gb {b_ * 1e3:9.1f} us {fl / b_ / 1e9:7.1f} TF/s  ({(a_ / b_ - 1) * 100:+.1f} %)  identical={same}", flush=True)
+                continue
             ms = bench(lambda: K.conv_forward(x, pk.wf, (k, k), Cout, nsplit=ns, ws=ws, out=out), iters)
             print(f"fwd   M={M:8d} C={Cin:5d} Cout={Cout:5d} k={k} split={ns:2d}: {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
         if what in ("wgrad", "all") and not slabs:
