@@ -1187,6 +1187,187 @@ __global__ __launch_bounds__(256, 2) void conv_halo_gb_kernel(ConvK p) {
     conv_halo_gb_tile<TM, WN, WMV, RELU, UP2>(p, smem, mt, nt, blockIdx.z);
 }
 
+// ---------------------------------------------------------------------------- the same for frames of 8 x 8 and 4 x 4 pixels
+// The recurrent convolutions of the first two generator stages (Generator.py:39,43: ConvGRUs on 4 x 4 / 8 x 8 latents) ran through
+// the tap-by-tap kernel: per (chunk, tap) one LDS-DMA gather of the activation tile, one of the weight tile, a counted wait and a
+// barrier -- K steps of pure issue / wait latency.  Here the M tile is G WHOLE frames (TM*64 / S^2 of them), whose zero-padded
+// footprints ((S+4) x (S+4) rows of 64 bytes per frame, PITCH = S + 4 whatever the filter size) sit in LDS for all 9 / 25 taps of a
+// channel chunk, and the weights come from L2 in fragment-major order as in conv_halo_gb_tile: no per-tap DMA, wait or barrier.
+// 16-byte slot swizzle: (line of the footprint) & 3 -- brute-forced conflict-free for both ds_read_b128 lane groups, every tap,
+// S = 8 (a 32-row sub-tile = 4 lines of one frame) and S = 4 (= 2 frames).
+template <int TM, int S> struct HaloGbsCfg {
+    static constexpr int PITCH = S + 4, FR = PITCH * PITCH;             // rows per frame footprint
+    static constexpr int G = TM * 64 / (S * S);                         // frames per tile
+    static constexpr int HG = (G * FR + 15) / 16;
+    static constexpr int HBYTES = HG * 1024;
+    static constexpr int EPI = 4 * 32 * 64 * 4;
+    static constexpr int LDSB = 2 * HBYTES + 1024 > EPI ? 2 * HBYTES + 1024 : EPI;
+};
+
+template <int TM, int S, bool RELU>
+__device__ __forceinline__ void conv_halo_gbs_tile(const ConvK& p, char* const smem, const int mt, const int nt, const int z) {
+    using T = bf16_t;
+    using Cfg = HaloGbsCfg<TM, S>;
+    constexpr int WN = 2, NWAVE = 4, BNt = 128;
+    constexpr int PITCH = Cfg::PITCH, FR = Cfg::FR, G = Cfg::G, HG = Cfg::HG, HBYTES = Cfg::HBYTES;
+    constexpr int NH = (HG + NWAVE - 1) / NWAVE;
+    constexpr int SS = S * S;
+    char* const hbuf0 = &smem[0];
+    char* const dump = &smem[2 * HBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = nt * BNt;
+    const int ft0 = mt * G, nframes = p.M / SS;
+    const int per = (p.kchunks + p.nsplit - 1) / p.nsplit;
+    const int cc_begin = z * per, cc_end = min(p.kchunks, cc_begin + per);
+    const int ntap2 = p.kh * p.kw;
+    constexpr unsigned esz = 2;
+    const int pad = p.kh >> 1, ext = S + 2 * pad;                      // footprint extent actually used by this filter
+
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int lrow = lane >> 2;
+    const unsigned ldb = (unsigned)p.ldi * esz;
+    const size_t base_b = (size_t)ft0 * SS * ldb;
+    const size_t left_b = p.in_bytes - base_b;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.in + base_b), 0, left_b > 0xfffffffeull ? 0xfffffffeu : (unsigned)left_b, 0x00020000);
+    const int nb32 = p.nb32;
+    const __amdgpu_buffer_rsrc_t rwq = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wq, 0, (unsigned)((size_t)ntap2 * p.kchunks * nb32 * 2048), 0x00020000);
+    unsigned hoff[NH];
+    int hq[NH];
+    bool hval[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int g = i * NWAVE + wu;
+        const int h = g * 16 + lrow;
+        const int fl = h / FR, r = h - fl * FR;
+        const int hy = r / PITCH, hx = r - hy * PITCH;
+        const int yin = hy - pad, xin = hx - pad;
+        hq[i] = (lane & 3) ^ (hy & 3);
+        hval[i] = g < HG && fl < G && ft0 + fl < nframes && hy < ext && hx < ext && (unsigned)yin < (unsigned)S && (unsigned)xin < (unsigned)S;
+        hoff[i] = (unsigned)((fl * S + yin) * S + xin) * ldb + hq[i] * 16;
+    }
+    auto dmaH = [&](int hb, int cc_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int g = i * NWAVE + wu;
+            char* dst_ = g < HG ? hbuf0 + hb * HBYTES + g * 1024 : dump;
+            const bool cv_ = cc_ * 32 + hq[i] * 8 < p.C;
+            dma16(rin, dst_, (hval[i] && cv_) ? hoff[i] + cc_ * 64 : 0xffffffffu);
+        }
+    };
+    const unsigned bvoff = (unsigned)(wn * 2 * 2048 + lane * 16);
+    const unsigned bnt = (unsigned)(nt * (BNt / 32)) * 2048u;
+    const unsigned brec = (unsigned)nb32 * 2048u;
+    auto ldBq = [&](bf16x8 (&b)[2][2], unsigned rec) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+                b[kk][tn] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rwq, bvoff, rec + (unsigned)(tn * 2048 + kk * 1024), 0));
+    };
+
+    f32x16 acc[TM][2];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = zacc;
+    }
+    // this lane's A rows: pixel pi = (wm*TM + tm)*32 + l31 of the tile -> (frame, y, x); sub-tile tm sits a compile-time number of
+    // footprint rows further (S = 8: 4 lines or a whole frame, S = 4: two frames); y & 3 is the same for every tm
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int pi0 = wm * (TM * 32) + l31;
+    const int f0 = pi0 / SS, y0 = (pi0 % SS) / S, x0 = pi0 % S;
+    const int arow0 = f0 * FR + y0 * PITCH + x0;
+    auto tmoff = [](int tm) constexpr -> int { return S == 8 ? ((tm >> 1) * FR + (tm & 1) * 4 * PITCH) * 64 : tm * 2 * FR * 64; };
+#ifdef DVD_EXP_NOMAIN
+    const int nsteps = 0;
+#else
+    const int nsteps = (cc_end - cc_begin) * ntap2;
+#endif
+    if (nsteps > 0) {
+        int m_cc = cc_begin, h_cc = cc_begin;
+        unsigned rec = (unsigned)m_cc * brec + bnt;                     // tap 0 of chunk m_cc; records are [tap][chunk]
+        const unsigned tapstep = (unsigned)p.kchunks * brec;
+        bf16x8 bq0[2][2], bq1[2][2];
+        dmaH(0, h_cc); ++h_cc;
+        ldBq(bq0, rec);
+        __builtin_amdgcn_s_waitcnt(0x0070 | (0xf << 8));                // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        int hb = 0, m_tap = 0, iy = 0, ix = 0;
+        auto step = [&](bf16x8 (&b)[2][2], bf16x8 (&bn)[2][2], int sidx) __attribute__((always_inline)) {
+            const bool more = sidx + 1 < nsteps;
+            const bool last_tap = m_tap + 1 == ntap2;
+            const bool issueH = m_tap == 0 && m_cc + 1 < cc_end;
+            unsigned nrec = more ? rec + tapstep : rec;
+            if (last_tap && more) nrec = (unsigned)(m_cc + 1) * brec + bnt;
+            const int swz = (y0 + iy) & 3;
+            const char* Ah = hbuf0 + hb * HBYTES + (arow0 + iy * PITCH + ix) * 64;
+            constexpr int NU = 2 * TM;
+            bf16x8 a[NU];
+            auto ldA = [&](int u) __attribute__((always_inline)) {
+                const int kk = u / TM, tm = u % TM, slot = kk * 2 + kh2;
+                a[u] = *reinterpret_cast<const bf16x8*>(Ah + tmoff(tm) + ((slot ^ swz) << 4));
+            };
+            ldA(0); ldA(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + 2 < NU) ldA(u + 2);
+                const int kk = u / TM, tm = u % TM;
+                if constexpr (RELU) a[u] = __builtin_bit_cast(bf16x8, relu16_bf16(__builtin_bit_cast(u32x4, a[u])));
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[kk][tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u == 0) {
+                    ldBq(bn, nrec);
+                    if (issueH) { dmaH(hb ^ 1, h_cc); ++h_cc; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            rec = nrec;
+            ++m_tap;
+            if (++ix == p.kw) { ix = 0; ++iy; }
+            if (last_tap) {
+                m_tap = 0; iy = 0; ix = 0; ++m_cc; hb ^= 1;
+                if (more) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        };
+        int sidx = 0;
+        for (; sidx + 1 < nsteps; sidx += 2) { step(bq0, bq1, sidx); step(bq1, bq0, sidx + 1); }
+        if (sidx < nsteps) step(bq0, bq1, sidx);
+    }
+    __syncthreads();
+
+    float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 64);
+    const int ecol = (lane & 7) * 8, erow = lane >> 3;
+    const long long row0 = (long long)ft0 * SS;
+    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, row0, [&](int tm, int j) __attribute__((always_inline)) {
+        const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;          // the tile's rows are G consecutive whole frames
+        return row0 + pi < p.M ? pi : -1;
+    });
+}
+
+template <int TM, int S, bool RELU>
+__global__ __launch_bounds__(256, 2) void conv_halo_gbs_kernel(ConvK p) {
+    __shared__ __attribute__((aligned(16))) char smem[HaloGbsCfg<TM, S>::LDSB];
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (bid >> 3);
+    }
+    int mt = bid / p.tilesN, nt = bid - mt * p.tilesN;
+    if (p.nmajor) { const int tilesM = gridDim.x / p.tilesN; nt = bid / tilesM; mt = bid - nt * tilesM; }
+    conv_halo_gbs_tile<TM, S, RELU>(p, smem, mt, nt, blockIdx.z);
+}
+
 // standard forward pack [tap][Cout][C] (bf16) -> fragment-major [tap][chunk][nb32][kk][lane][8] (zeros in every padded position)
 struct FragK { const bf16_t* w; bf16_t* wq; int ntaps, Cout, C, kchunks, nb32; };
 __global__ void fragment_major_kernel(FragK p) {
@@ -2002,7 +2183,7 @@ extern "C" long long dvd_prof_report(int kind, double* total_ms, double* total_f
 extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) { return dvd_conv_forward_gru(d, nullptr, stream); }
 
 // Validates a forward / backward-data request and derives the kernel parameters and the variant that serves it.
-struct ConvPlan { long long M; bool halo, thin, wide, big; };
+struct ConvPlan { long long M; bool halo, thin, wide, big, smallf; };
 static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan& pl) {
     if (!d || !d->in || !d->w || (!d->ws && (!d->out || d->nsplit > 1))) return DVD_E_ARG;
     if (g && (d->ws || d->nsplit > 1 || (g->h & 7))) return DVD_E_ARG;
@@ -2040,8 +2221,14 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     static const int use_halo = getenv("DVD_CONV_HALO") ? atoi(getenv("DVD_CONV_HALO")) : 1;
     const bool halo = use_halo && pow2 && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->W >= 16 && d->H >= 16 &&
                       p.nsplit <= p.kchunks * d->kt;
+    // frames of 4 x 4 / 8 x 8 pixels (bf16, 2-D taps, no upsample): whole-frame footprints in LDS, weights from L2 -- needs the
+    // fragment-major image
+    static const int use_small = getenv("DVD_CONV_SMALLF") ? atoi(getenv("DVD_CONV_SMALLF")) : 1;
+    const bool smallf = use_small && !halo && pow2 && d->dtype == DVD_BF16 && d->wq && d->kt == 1 && d->T == 1 && !d->up2 &&
+                        d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->H == d->W && (d->W == 4 || d->W == 8) &&
+                        p.nsplit <= p.kchunks && M < (1ll << 24);
     const bool thin = halo && d->dtype == DVD_BF16 && d->Cout <= 64 && cdiv(M, 256) * (long long)p.nsplit >= 512;
-    const bool wide = !halo && d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
+    const bool wide = !halo && !smallf && d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
     p.tilesN = wide ? (d->Cout + 255) / 256 : thin ? 1 : (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};
@@ -2055,7 +2242,7 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
         p.in_bytes = inb; p.w_bytes = (unsigned)wb;
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
         static const int nmaj = getenv("DVD_CONV_NMAJOR") ? atoi(getenv("DVD_CONV_NMAJOR")) : 1;
-        p.nmajor = nmaj && !halo && wb > inb && wb > (4u << 20);      // weights beyond one L2
+        p.nmajor = nmaj && !halo && wb > inb && wb > (4u << 20);      // weights beyond one L2 (also for the small-frame halo kernel)
         // halo kernel: with several N tiles and weights well beyond one L2, a run of workgroups that shares the weight tile
         // (and streams the activations once per N tile) misses less than one that shares the footprint and cycles through
         // all the weights: 1272 -> 1355 TF/s on 786 k x 256 -> 1536 (19.7 MB of weights); neutral from 5 MiB, -1.5 % at 4.9 MB
@@ -2073,11 +2260,11 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
         const int F = d->frames;
         const bool lines = (F % bmt == 0) || (bmt % F == 0 && d->W % (bmt / F) == 0);
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
-        if (use_pm && !halo && pow2 && d->kt == 1 && d->T == 1 && !d->up2 && d->kh >= 3 && d->H <= 8 && lines &&
+        if (use_pm && !halo && !smallf && pow2 && d->kt == 1 && d->T == 1 && !d->up2 && d->kh >= 3 && d->H <= 8 && lines &&
             (size_t)M * (size_t)(d->ldi > 3 * d->Cout ? d->ldi : 3 * d->Cout) * 4 < (1ull << 31))     // every epilogue offset from row 0 fits
             p.pm = F;
     }
-    pl.M = M; pl.halo = halo; pl.thin = thin; pl.wide = wide; pl.big = big;
+    pl.M = M; pl.halo = halo; pl.thin = thin; pl.wide = wide; pl.big = big && !(smallf && d->W == 4); pl.smallf = smallf;
     return DVD_OK;
 }
 
@@ -2091,7 +2278,17 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
     hipStream_t st = (hipStream_t)stream;
-    prof.r.variant = halo ? (thin ? 3 : big ? 1 : 2) : (wide ? 6 : big ? 5 : 4);
+    prof.r.variant = halo ? (thin ? 3 : big ? 1 : 2) : pl.smallf ? (big ? 1 : 2) : (wide ? 6 : big ? 5 : 4);
+    if (pl.smallf) {
+        const int S_ = d->W, Gf = (big ? 256 : 128) / (S_ * S_);
+        grid = dim3(cdiv(d->frames, Gf) * p.tilesN, 1, p.nsplit);
+#define LAUNCH_GBS(TM_, SZ_) do { if (d->relu_in) conv_halo_gbs_kernel<TM_, SZ_, true><<<grid, 256, 0, st>>>(p);   \
+                                  else conv_halo_gbs_kernel<TM_, SZ_, false><<<grid, 256, 0, st>>>(p); } while (0)
+        if (S_ == 8) { if (big) LAUNCH_GBS(4, 8); else LAUNCH_GBS(2, 8); }
+        else LAUNCH_GBS(2, 4);
+#undef LAUNCH_GBS
+        return launch_status();
+    }
     if (halo) {
 #define LAUNCH_HALO2(TT, TM_, WN_, RL_)                                                             \
         do { if (d->up2) conv_halo_kernel<TT, TM_, WN_, RL_, true><<<grid, 128 * WN_, 0, st>>>(p);      \
@@ -2304,8 +2501,9 @@ extern "C" int dvd_conv_wants_fragment_major(const dvd_conv_desc* d) {
     ConvK p; ConvPlan pl;
     dvd_conv_desc t = *d;
     if (!t.w) t.w = t.in;                 // (only the geometry matters here)
+    t.wq = t.w;                           // "if the image were supplied"
     if (conv_plan(&t, nullptr, p, pl) != DVD_OK) return 0;
-    return (pl.halo && d->dtype == DVD_BF16) ? 1 : 0;
+    return ((pl.halo || pl.smallf) && d->dtype == DVD_BF16) ? 1 : 0;
 }
 
 extern "C" int dvd_pack_conv_weight(int dtype, const float* w, const float* sigma, int Cout, int Cin, int ntaps,

@@ -242,12 +242,17 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
     // round 3 (gate math batched in the conv epilogue, tools/gru_microbench.py sweep): a 5 x 5 conv with a short K loop
     // (C = 128: 100 steps) no longer gains from a split plus gate kernel once it has 512 tiles (S = 32, h = 128:
     // 180.5 / 208.7 -> 171.0 / 196.4 us per step forward / backward); the long loops (C = 512: 400 steps) still do
-    const long long target = target_env ? target_env : (ntaps <= 9 || nk < 200 ? 512 : 1024);
+    // (round 4, weights from L2: nk = 200 -- the d[u|r] conv of gru3.l2 -- is better off unsplit too: 187.6 -> 174.2 us per step)
+    const long long target = target_env ? target_env : (ntaps <= 9 || nk <= 200 ? 512 : 1024);
     long long ns = (target + tiles - 1) / tiles;
     // (cap: 8 since the pixel-major tile order skips the out-of-frame filter rows of the 4 x 4 convs -- their K loops are
     //  shorter, and 16 slabs of 2 MB cost more in the gate kernels than they return: 39.1 / 39.4 -> 34.3 / 34.1 us per step)
-    static const long long cap = getenv("DVD_NS_CAP") ? atoll(getenv("DVD_NS_CAP")) : 8;
+    static const bool cap_env = getenv("DVD_NS_CAP") != nullptr;
+    static const long long cap = cap_env ? atoll(getenv("DVD_NS_CAP")) : 8;
     if (ns > cap) ns = cap;
+    // (round 4, whole-frame footprint kernel: the 3 x 3 layers on 8 x 8 frames -- 18 K steps per slice at 4 -- lose more in the gate
+    //  kernel's eight slabs than the fuller launch returns: 114.6 / 111.8 -> 100.6 / 102.1 us per step for gru1.l0 / l2, forward + backward)
+    if (!cap_env && ntaps <= 9 && M >= 4096 && ns > 4) ns = 4;
     if (ns > nk) ns = nk;
     if (ns < 1) ns = 1;
     return (int)ns;

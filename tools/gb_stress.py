@@ -13,6 +13,10 @@ CASES = [  # frames, S, Cin, Cout, k, up2, relu, nsplit
     (64, 32, 128, 128, 3, 0, 0, 1), (64, 16, 256, 256, 3, 0, 0, 1), (64, 16, 256, 256, 3, 0, 0, 2),
     (512, 64, 64, 64, 3, 0, 0, 1), (512, 64, 8, 64, 3, 0, 0, 1), (256, 32, 256, 128, 3, 1, 1, 1), (512, 64, 128, 64, 3, 1, 1, 1),
     (256, 32, 128, 128, 3, 0, 1, 1), (64, 32, 256, 512, 5, 0, 0, 1), (3072, 16, 256, 256, 3, 0, 0, 1),
+    # frames of 8 x 8 / 4 x 4 pixels (whole-frame footprints): split and unsplit, 256- and 128-row tiles, ragged frame counts
+    (64, 8, 512, 1024, 5, 0, 0, 4), (64, 8, 512, 512, 5, 0, 0, 8), (64, 8, 256, 512, 3, 0, 0, 4), (64, 8, 256, 256, 3, 0, 0, 1),
+    (3072, 8, 256, 1536, 5, 0, 0, 1), (3072, 8, 256, 256, 3, 0, 1, 1), (64, 4, 512, 1024, 5, 0, 0, 8), (64, 4, 256, 512, 3, 0, 0, 8),
+    (3072, 4, 256, 768, 3, 0, 0, 1), (61, 8, 64, 96, 3, 0, 0, 1), (13, 4, 40, 72, 5, 0, 1, 2),
 ]
 
 

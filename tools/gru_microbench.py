@@ -51,6 +51,9 @@ def setup(name, S, cin, hid, k, B, T, dev, dt, lib):
     d.gx_stride = M * 3 * hid
     d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
     d.wd_ur, d.wd_o = pur.wd.data_ptr(), po.wd.data_ptr()
+    if os.environ.get("GB", "1") != "0":       # fragment-major weight images, as functional.ConvGRULayer supplies them
+        d.w_ur_q, d.w_o_q = pur.fragment_major("wf").data_ptr(), po.fragment_major("wf").data_ptr()
+        d.wd_ur_q, d.wd_o_q = pur.fragment_major("wd").data_ptr(), po.fragment_major("wd").data_ptr()
     d.h_all, d.u_all, d.r_all, d.o_all, d.hr_all = (t.data_ptr() for t in bufs)
     d.h32, d.ws = h32.data_ptr(), ws.data_ptr()
     dh = (torch.randn(T, M, hid, device=dev) * 0.1).to(dt)
@@ -155,27 +158,9 @@ def main():
     lib = L.lib()
     tot_f = tot_b = 0.0
     for name, S, cin, hid, k in [LAYERS[i] for i in sel]:
-        M = B * S * S
-        gx = (torch.randn(T, M, 3 * hid, device=dev) * 0.5).to(dt)
-        pur = K.PackedConv(dt, 2 * hid, hid, (k, k), dev).fill(torch.randn(2 * hid, hid, k, k, device=dev) * (0.5 / (hid * k * k) ** 0.5))
-        po = K.PackedConv(dt, hid, hid, (k, k), dev).fill(torch.randn(hid, hid, k, k, device=dev) * (0.5 / (hid * k * k) ** 0.5))
-        mk = lambda: torch.empty(T, M, hid, dtype=dt, device=dev)
-        h_all, u_all, r_all, o_all, hr_all = mk(), mk(), mk(), mk(), mk()
-        h32 = torch.empty(2, M, hid, dtype=torch.float32, device=dev)
-        ntaps = k * k
+        M, ntaps = B * S * S, k * k
+        d, keep = setup(name, S, cin, hid, k, B, T, dev, dt, lib)
         ns = [lib.dvd_conv_pick_nsplit(L.BF16, C.c_longlong(M), co, ci, ntaps) for co, ci in ((2 * hid, hid), (hid, hid), (hid, 2 * hid))]
-        ws = torch.empty(max(ns[0] * 2, ns[1], ns[2]) * M * hid, dtype=torch.float32, device=dev)
-        d = L.GruDesc()
-        d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.BF16, T, B, S, S, hid, k
-        d.gx_stride = M * 3 * hid
-        d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
-        d.wd_ur, d.wd_o = pur.wd.data_ptr(), po.wd.data_ptr()
-        d.h_all, d.u_all, d.r_all, d.o_all, d.hr_all = (t.data_ptr() for t in (h_all, u_all, r_all, o_all, hr_all))
-        d.h32, d.ws = h32.data_ptr(), ws.data_ptr()
-        dh = (torch.randn(T, M, hid, device=dev) * 0.1).to(dt)
-        dg = torch.empty(T, M, 3 * hid, dtype=dt, device=dev)
-        carry = torch.empty(M, hid, dtype=torch.float32, device=dev)
-        d.dh_out, d.dg, d.carry = dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         tf = timed(lambda: L.check(lib.dvd_convgru_layer_forward(C.byref(d), st)), iters)
         tb = timed(lambda: L.check(lib.dvd_convgru_layer_backward(C.byref(d), st)), iters)
