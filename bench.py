@@ -226,12 +226,17 @@ def main():
     if not a.no_kernel_prof:
         lib.dvd_prof_report_variants.restype = C.c_longlong
         res, by_kernel = {}, {}
-        vnames = {0: {1: "conv_halo_kernel<bf16, 256x128 tile>", 2: "conv_halo_kernel<bf16, 128x128 tile>",
-                      3: "conv_halo_kernel<bf16, 256x64 tile>", 4: "conv_igemm_kernel<bf16, 128x128 tile>",
-                      5: "conv_igemm_kernel<bf16, 256x128 tile>", 6: "conv_igemm_kernel<bf16, 256x256 tile, 8 waves>"},
+        # bf16: the halo-staged kernels read their weights from L2 (conv_halo_gb_kernel; conv_halo_gbs_kernel on 4x4 / 8x8 frames);
+        # exact mode runs the LDS-staged conv_halo_kernel under the same variant numbers
+        hk = "conv_halo_gb_kernel" if a.dtype == "bf16" else "conv_halo_kernel"
+        vnames = {0: {1: hk + "<%s, 256x128 tile>" % a.dtype, 2: hk + "<%s, 128x128 tile>" % a.dtype,
+                      3: hk + "<%s, 256x64 tile>" % a.dtype, 4: "conv_igemm_kernel<%s, 128x128 tile>" % a.dtype,
+                      5: "conv_igemm_kernel<%s, 256x128 tile>" % a.dtype, 6: "conv_igemm_kernel<bf16, 256x256 tile, 8 waves>",
+                      7: "conv_halo_gbs_kernel<bf16, 256x128 tile, 8x8 frames>",
+                      8: "conv_halo_gbs_kernel<bf16, 128x128 tile, 4x4 / 8x8 frames>"},
                   1: {1: "conv_wgrad_row_kernel", 2: "conv_wgrad_kernel"}}
         for kind, name in ((0, "conv_igemm"), (1, "conv_wgrad")):
-            NV = 8
+            NV = 10
             nn, tms, fl = (C.c_longlong * NV)(), (C.c_double * NV)(), (C.c_double * NV)()
             lib.dvd_prof_report_variants(kind, NV, nn, tms, fl)          # totals of the instrumented step, per kernel variant
             mk = lambda v: {"launches": int(nn[v]), "ms": tms[v],
@@ -246,7 +251,7 @@ def main():
         F = F_GFLOP_PER_CLIP.get((a.ch, a.frames, a.size))
         dom = res["conv_igemm"]
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        roof = {"bound": "mfma", "kernel": "conv_halo_kernel + conv_igemm_kernel <bf16> (forward + backward-data convolutions)" if a.dtype == "bf16" else "conv_halo_kernel + conv_igemm_kernel <f32>",
+        roof = {"bound": "mfma", "kernel": "conv_halo_gb_kernel + conv_halo_gbs_kernel + conv_igemm_kernel <bf16> (forward + backward-data convolutions)" if a.dtype == "bf16" else "conv_halo_kernel + conv_igemm_kernel <f32>",
                 "achieved": round(dom["tflops"], 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(dom["tflops"] / peak, 4), "traffic": hbm_traffic(a, batch),
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),

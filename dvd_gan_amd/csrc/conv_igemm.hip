@@ -2145,7 +2145,7 @@ extern "C" void dvd_prof_enable(int on) {
 // kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Drains the records of `kind` and returns the number of
 // launches; n / ms / flops (each [nvar] or NULL) receive the per-variant totals -- kind 0: 1 = conv_halo 256 x 128,
 // 2 = conv_halo 128 x 128, 3 = conv_halo 256 x 64 (thin outputs), 4 = conv_igemm 128 x 128, 5 = conv_igemm 256 x 128,
-// 6 = conv_igemm 256 x 256 (8 waves); kind 1: 1 = filter-row kernel, 2 = one-tap kernel; index 0 = everything.
+// 6 = conv_igemm 256 x 256 (8 waves), 7 / 8 = whole-frame footprint kernel (4 x 4 / 8 x 8 frames) 256 x 128 / 128 x 128; kind 1: 1 = filter-row kernel, 2 = one-tap kernel; index 0 = everything.
 // If the environment variable DVD_PROF_CSV is set, every drained record is appended to that file.
 extern "C" long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops) {
     std::lock_guard<std::mutex> l(g_prof_mu);
@@ -2278,7 +2278,7 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
     hipStream_t st = (hipStream_t)stream;
-    prof.r.variant = halo ? (thin ? 3 : big ? 1 : 2) : pl.smallf ? (big ? 1 : 2) : (wide ? 6 : big ? 5 : 4);
+    prof.r.variant = halo ? (thin ? 3 : big ? 1 : 2) : pl.smallf ? (big ? 7 : 8) : (wide ? 6 : big ? 5 : 4);
     if (pl.smallf) {
         const int S_ = d->W, Gf = (big ? 256 : 128) / (S_ * S_);
         grid = dim3(cdiv(d->frames, Gf) * p.tilesN, 1, p.nsplit);

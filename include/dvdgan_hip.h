@@ -43,7 +43,8 @@ void dvd_prof_enable(int on);
 long long dvd_prof_report(int kind, double* total_ms, double* total_flops);
 /* The same, split by kernel variant: n / ms / flops are arrays of nvar entries (or NULL); entry 0 = all launches of `kind`,
  * kind 0: 1 = conv_halo 256x128 tile, 2 = conv_halo 128x128, 3 = conv_halo 256x64, 4 = conv_igemm 128x128,
- * 5 = conv_igemm 256x128, 6 = conv_igemm 256x256; kind 1: 1 = filter-row kernel, 2 = one-tap kernel. */
+ * 5 = conv_igemm 256x128, 6 = conv_igemm 256x256, 7 / 8 = whole-frame footprint kernel (4x4 / 8x8 frames) 256x128 / 128x128;
+ * kind 1: 1 = filter-row kernel, 2 = one-tap kernel. */
 long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops);
 const char* dvd_strerror(int code);
 
