@@ -198,7 +198,9 @@ __device__ __forceinline__ void epi_run(Stage stage, Load load, Compute compute)
 // `ep`: the wave's LDS staging block (32 x 64 floats); col: first of this lane's 8 output columns; row0: first row every
 // row of this workgroup's tile is relative to (the buffer descriptors start there, offsets stay 32-bit); relrow(tm, j): this
 // lane's row of round j of sub-tile tm, relative to row0, or a negative number when it lies past M.
-template <typename T, int TM, class RelRow>
+// DEEP: deeper operand pipelines for the gate epilogues (kernels whose accumulators live in the unified register file can spend the
+// registers of already-staged sub-tiles on operands in flight)
+template <typename T, int TM, int DEEP = 0, class RelRow>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][2], float* ep, int lane, int col, int z,
                                               long long row0, RelRow relrow) {
     constexpr unsigned esz = sizeof(T);
@@ -264,7 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
         return;
     }
     if (mode == 2) {                // o = tanh(acc + gx_o);  h = h_prev (1 - u) + o u          (ConvGRU.py:50-52)
-        constexpr int D = 1;
+        constexpr int D = (kB && DEEP) ? DEEP : 1;
         const int h = p.g.h;
         const bool c32 = p.g.h32p != nullptr;
         const auto rgx = epi_rsrc(p.g.gx, row0, p.g.ldg * esz, rows), ru = epi_rsrc(p.g.u_in, row0, h * esz, rows);
@@ -299,7 +301,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
         return;
     }
     if (mode == 3) {                // BPTT: acc = d(h*r);  carry += acc*r;  d(pre_r) = acc*h_prev*r(1-r)   (gru.hip gru_bwd_r)
-        constexpr int D = kB ? 2 : 1;
+        constexpr int D = kB ? (DEEP ? 3 : 2) : 1;
         const int h = p.g.h;
         const auto rr_ = epi_rsrc(p.g.r, row0, h * esz, rows), rhp = epi_rsrc(p.g.hprev, row0, h * esz, rows);
         const auto rcy = epi_rsrc(p.g.h32n, row0, h * 4, rows), rdg = epi_rsrc(p.g.o, row0, p.g.ldg * esz, rows);
@@ -324,7 +326,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
         return;
     }
     if (mode == 5) {                // BPTT: mode 4 followed by the first half of the NEXT step to process (gru_bwd_out):
-        constexpr int D = 1;        // dh = carry + acc + dh_out;  d(pre_o), d(pre_u) of that step;  carry = dh (1 - u)
+        constexpr int D = (kB && DEEP) ? DEEP : 1;        // dh = carry + acc + dh_out;  d(pre_o), d(pre_u) of that step;  carry = dh (1 - u)
         const int h = p.g.h;
         const auto rcy = epi_rsrc(p.g.h32n, row0, h * 4, rows), rdh = epi_rsrc(p.g.gx, row0, h * esz, rows);
         const auto ru = epi_rsrc(p.g.u_in, row0, h * esz, rows), rog = epi_rsrc(p.g.hr, row0, h * esz, rows);
@@ -978,6 +980,9 @@ __global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
 // point where the compiler waits for step s's own fragments (hipcc drains vmcnt(0) there while an LDS-DMA may be pending).
 // waves: WMV (M) x WN (N), wave tile (TM*32 pixels) x 64 columns: 4 x 2 x 2 = the 256 x 128 tile, 2 x 2 x 2 = 128 x 128 (launches with
 // few rows), 2 x 1 x 4 = 256 x 64 (thin outputs)
+#ifndef DVD_GB_EPI_DEEP
+#define DVD_GB_EPI_DEEP 0
+#endif
 template <int TM, int WN, int WMV, bool UP2> struct HaloGbCfg {
     static constexpr int PITCH = HaloGeo<UP2>::PITCH;
     static constexpr int NWAVE = WMV * WN;
@@ -1168,7 +1173,7 @@ __device__ __forceinline__ void conv_halo_gb_tile(const ConvK& p, char* const sm
     float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     const long long frame_row0 = (long long)ft * (p.H * p.W);
-    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, frame_row0, [&](int tm, int j) __attribute__((always_inline)) {
+    conv_epilogue<T, TM, DVD_GB_EPI_DEEP>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, frame_row0, [&](int tm, int j) __attribute__((always_inline)) {
         const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;
         return (y0 + (pi >> 4)) * p.W + x0 + (pi & 15);
     });
@@ -1349,7 +1354,7 @@ __device__ __forceinline__ void conv_halo_gbs_tile(const ConvK& p, char* const s
     float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     const long long row0 = (long long)ft0 * SS;
-    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, row0, [&](int tm, int j) __attribute__((always_inline)) {
+    conv_epilogue<T, TM, DVD_GB_EPI_DEEP>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, row0, [&](int tm, int j) __attribute__((always_inline)) {
         const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;          // the tile's rows are G consecutive whole frames
         return row0 + pi < p.M ? pi : -1;
     });
