@@ -1089,31 +1089,42 @@ __device__ __forceinline__ void conv_halo_gb_tile(const ConvK& p, char* const sm
     const int nsteps = (oc_end - oc_begin) * ntap2;
 #endif
     if (nsteps > 0) {
-        // running (chunk, dt, tap) of the step being multiplied and of the next weight record / footprint to fetch
+        // running (chunk, dt) of the step being multiplied / of the next footprint, and the FETCH iterator of the weight records
+        // (memory order [tap][chunk]), which runs GB_DIST K steps ahead and stops at the last record (the trailing requests re-read it:
+        // they are UNCONDITIONAL so that the compiler's counted waits know them outstanding -- behind a branch hipcc assumes the
+        // smaller count and drains the prefetch in the middle of a step)
+#ifdef DVD_GB_DIST2
+        constexpr int GB_DIST = 2;
+#else
+        constexpr int GB_DIST = 1;
+#endif
         int m_cc = oc_begin / p.kt, m_it = oc_begin - m_cc * p.kt;
         int h_cc = m_cc, h_it = m_it;
-        unsigned rec = ((unsigned)(m_it * ntap2) * p.kchunks + m_cc) * brec + bnt;      // record of step 0: tap index (it * ntap2 + tap)
-        // record order in memory is [tap][chunk]: stepping the tap moves by kchunks records
-        const unsigned tapstep = (unsigned)p.kchunks * brec;
+        int f_cc = m_cc, f_it = m_it, f_tap = 0, f_left = nsteps;
+        auto frec = [&]() __attribute__((always_inline)) -> unsigned {
+            return ((unsigned)(f_it * ntap2 + f_tap) * p.kchunks + f_cc) * brec + bnt;
+        };
+        auto fadv = [&]() __attribute__((always_inline)) {
+            if (f_left > 1) { --f_left; if (++f_tap == ntap2) { f_tap = 0; if (++f_it == p.kt) { f_it = 0; ++f_cc; } } }
+        };
         bf16x8 bq0[2][2], bq1[2][2];
         dmaH(0, h_cc, h_it);
         if (++h_it == p.kt) { h_it = 0; ++h_cc; }
-        ldBq(bq0, rec);
+        ldBq(bq0, frec()); fadv();
+#ifdef DVD_GB_DIST2
+        bf16x8 bq2[2][2];
+        ldBq(bq1, frec()); fadv();
+#endif
         __builtin_amdgcn_s_waitcnt(0x0070 | (0xf << 8));                // vmcnt(0): footprint 0 (this wave's part) landed
         __builtin_amdgcn_s_barrier();
+#ifdef DVD_GB_PRIO
+        if (__builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);   // the second workgroup of a CU
+#endif
         int hb = 0, m_tap = 0, m_oc = oc_begin, iy = 0, ix = 0;
         auto step = [&](bf16x8 (&b)[2][2], bf16x8 (&bn)[2][2], int sidx) __attribute__((always_inline)) {
             const bool more = sidx + 1 < nsteps;
             const bool last_tap = m_tap + 1 == ntap2;
             const bool issueH = m_tap == 0 && m_oc + 1 < oc_end;
-            // record of the NEXT step (the last step re-reads its own: the request is UNCONDITIONAL so that the compiler's counted
-            // waits know it is outstanding -- behind a branch it assumes the smaller count and drains the prefetch mid-step)
-            unsigned nrec = more ? rec + tapstep : rec;
-            if (last_tap && more) {
-                int n_cc = m_cc, n_it = m_it + 1;
-                if (n_it == p.kt) { n_it = 0; ++n_cc; }
-                nrec = ((unsigned)(n_it * ntap2) * p.kchunks + n_cc) * brec + bnt;
-            }
             const int hy = UP2 ? ((py0 + iy - pad) >> 1) + cpad : py0 + iy;
             const int hx = UP2 ? ((px + ix - pad) >> 1) + cpad : px + ix;
             const int swz = G::sw(hy, hx);
@@ -1138,20 +1149,19 @@ __device__ __forceinline__ void conv_halo_gb_tile(const ConvK& p, char* const sm
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == 0) {
                     // behind the first MFMA pair (the compiler's wait for THIS step's fragments sits in front of it): request the
-                    // next step's fragments, and at the first tap of a chunk the next chunk's footprint
+                    // fragments GB_DIST steps ahead, and at the first tap of a chunk the next chunk's footprint
 #ifndef DVD_EXP_NODMA
-                    ldBq(bn, nrec);
+                    ldBq(bn, frec()); fadv();
                     if (issueH) { dmaH(hb ^ 1, h_cc, h_it); if (++h_it == p.kt) { h_it = 0; ++h_cc; } }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            rec = nrec;
             ++m_tap;
             if (++ix == p.kw) { ix = 0; ++iy; }
             if (last_tap) {
                 // chunk boundary: every wave has finished reading footprint hb (it is overwritten one chunk from now) and has seen
-                // its own part of footprint hb ^ 1 land (the drain in front of this chunk's second step): one barrier per chunk
+                // its own part of footprint hb ^ 1 land (the in-order drain in front of the steps since): one barrier per chunk
                 m_tap = 0; iy = 0; ix = 0; ++m_oc; hb ^= 1;
                 if (++m_it == p.kt) { m_it = 0; ++m_cc; }
                 if (more) {
@@ -1165,8 +1175,14 @@ __device__ __forceinline__ void conv_halo_gb_tile(const ConvK& p, char* const sm
             }
         };
         int sidx = 0;
+#ifdef DVD_GB_DIST2
+        for (; sidx + 2 < nsteps; sidx += 3) { step(bq0, bq2, sidx); step(bq1, bq0, sidx + 1); step(bq2, bq1, sidx + 2); }
+        if (sidx < nsteps) { step(bq0, bq2, sidx); ++sidx; }
+        if (sidx < nsteps) { step(bq1, bq0, sidx); ++sidx; }
+#else
         for (; sidx + 1 < nsteps; sidx += 2) { step(bq0, bq1, sidx); step(bq1, bq0, sidx + 1); }
         if (sidx < nsteps) step(bq0, bq1, sidx);
+#endif
     }
     __syncthreads();
 
@@ -1991,7 +2007,7 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
 }
 
 // reduction of the row kernel's partial tiles: dw[co][ci][iy*KW + t] += sum over slices
-struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, BNc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; };
+struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, BNc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; int overwrite; };
 // sum over the slices of four consecutive partial-tile elements (16-byte loads, four slices requested before the first addition;
 // slice order kept): the reduce kernels stream the whole workspace once and were running at 2.5 TB/s with scalar loads
 __device__ __forceinline__ f32x4 slice_sum4(const float* ws, int nslice, size_t stride, size_t off) {
@@ -2024,7 +2040,7 @@ __global__ void wgrad_row_reduce_kernel(WgRowRedK p) {
     float* d = p.dw + co * p.s_co + ci * p.s_ci + (iy * p.KW + t) * p.s_tap;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (ci + j < p.Cin_real) d[j * p.s_ci] += a[j];
+        if (ci + j < p.Cin_real) d[j * p.s_ci] = p.overwrite ? a[j] : d[j * p.s_ci] + a[j];
 }
 
 // bias gradient of the row kernel's workspace path: dbias[co] += sum over (slice, filter row of the centre time slab, ci tile) of the
@@ -2064,7 +2080,7 @@ __global__ __launch_bounds__(1024) void wgrad_row_bias_reduce_kernel(WgBiasRedK 
 }
 
 // Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
-struct WgRedK { const float* ws; float* dw; int nslice, gx, gx_per_tap, tiles_ci, BMc, BNc, Cout, Cin_real; long long s_co, s_ci, s_tap; };
+struct WgRedK { const float* ws; float* dw; int nslice, gx, gx_per_tap, tiles_ci, BMc, BNc, Cout, Cin_real; long long s_co, s_ci, s_tap; int overwrite; };
 __global__ void wgrad_reduce_kernel(WgRedK p) {
     const int tile_elems = p.BMc * p.BNc;
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -2081,7 +2097,7 @@ __global__ void wgrad_reduce_kernel(WgRedK p) {
     float* d = p.dw + co * p.s_co + ci * p.s_ci + tap * p.s_tap;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (ci + j < p.Cin_real) d[j * p.s_ci] += a[j];
+        if (ci + j < p.Cin_real) d[j * p.s_ci] = p.overwrite ? a[j] : d[j * p.s_ci] + a[j];
 }
 
 // ============================================================================ weight packing
@@ -2437,6 +2453,12 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     if (rc != DVD_OK) return rc;
     const int ntaps = d->kt * d->kh * d->kw;
     if (d->ws && msplit > 1) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw
+    const int overwrite = d->overwrite != 0;       // dw = result instead of dw += result (the caller need not zero it)
+    if (overwrite) {
+        if (d->s_tap != 1 || d->s_ci != ntaps || d->s_co != (long long)d->Cin_real * ntaps) return DVD_E_ARG;   // dense [co][ci][tap] only
+        if (!p.ws && hipMemsetAsync(d->dw, 0, (size_t)d->Cout * d->Cin_real * ntaps * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return DVD_E_LAUNCH;                   // single slice: the kernel adds with atomics
+    }
     p.wsb = (p.ws && mode == 1) ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) : nullptr;
     ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
@@ -2463,7 +2485,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
 #undef LAUNCH_ROW_W
         if (p.ws) {
             WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, tb * 64, d->kw, p.Cout, p.Cin_real,
-                        p.s_co, p.s_ci, p.s_tap};
+                        p.s_co, p.s_ci, p.s_tap, overwrite};
             const long long n = (long long)grid.x * r.KW * r.BMc * r.BNc;
             wgrad_row_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
             if (p.dbias) {
@@ -2480,7 +2502,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     } else conv_wgrad_kernel<float, 2, 2><<<grid, NT, 0, st>>>(p);
     if (p.ws) {
         WgRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co * p.tiles_ci, p.tiles_ci, ta * 64, tb * 64, p.Cout,
-                 p.Cin_real, p.s_co, p.s_ci, p.s_tap};
+                 p.Cin_real, p.s_co, p.s_ci, p.s_tap, overwrite};
         const long long n = (long long)grid.x * r.BMc * r.BNc;
         wgrad_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
     }

@@ -56,13 +56,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 }
 
 // mean / rstd from the sums (training) or from the running buffers (eval); running-stat update.
-__global__ void bn_finalize_kernel(const double* sums, double n, int C, float eps, float momentum, int training,
-                                   float* mean, float* rstd, float* run_mean, float* run_var) {
+__global__ void bn_finalize_kernel(double* sums, double n, int C, float eps, float momentum, int training,
+                                   float* mean, float* rstd, float* run_mean, float* run_var, int rezero) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (training) {
         double s1 = 0, s2 = 0;
         for (int r = 0; r < DVD_BN_NREP; ++r) { s1 += sums[(size_t)r * 2 * C + c]; s2 += sums[(size_t)r * 2 * C + C + c]; }
+        if (rezero)                                // persistent workspace: left zeroed for the next statistics pass
+            for (int r = 0; r < DVD_BN_NREP; ++r) { sums[(size_t)r * 2 * C + c] = 0.0; sums[(size_t)r * 2 * C + C + c] = 0.0; }
         const double m = s1 / n;
         double var = s2 / n - m * m;
         if (var < 0) var = 0;
@@ -507,11 +509,11 @@ extern "C" int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int
     return launch_status();
 }
 
-extern "C" int dvd_bn_finalize(const double* sums, long long rows, int C, float eps, float momentum, int training,
-                               float* mean, float* rstd, float* run_mean, float* run_var, void* stream) {
+extern "C" int dvd_bn_finalize(double* sums, long long rows, int C, float eps, float momentum, int training,
+                               float* mean, float* rstd, float* run_mean, float* run_var, int rezero, void* stream) {
     if (!mean || !rstd || C <= 0 || (training ? !sums : (!run_mean || !run_var))) return DVD_E_ARG;
     bn_finalize_kernel<<<cdiv(C, 128), 128, 0, S_>>>(sums, (double)rows, C, eps, momentum, training, mean, rstd,
-                                                     run_mean, run_var);
+                                                     run_mean, run_var, rezero);
     return launch_status();
 }
 

@@ -57,19 +57,27 @@ class QKVConv(torch.autograd.Function):
         qkv = K.conv_forward(x, spec.pack.wf, (1, 1), ctot, bias=bias)
         ctx.save_for_backward(x, wq, wk, wv)
         ctx.spec, ctx.dq, ctx.dqp = spec, dq, dqp
+        ctx.params = (wq, bq, wk, bk, wv, bv)
         return qkv
 
     @staticmethod
     def backward(ctx, dqkv):
         x, wq, wk, wv = ctx.saved_tensors
+        wq_, bq_, wk_, bk_, wv_, bv_ = ctx.params
         spec, dq, dqp = ctx.spec, ctx.dq, ctx.dqp
         dqkv = dqkv.contiguous()
         C_ = spec.cin
         dx = K.conv_forward(dqkv, spec.pack.wd, (1, 1), spec.pack.cip) if ctx.needs_input_grad[0] else None
-        outs = []
         need_w = ctx.needs_input_grad[1]
+        parts = ((wq_, bq_, 0, dq), (wk_, bk_, dqp, dq), (wv_, bv_, 2 * dqp, C_))
+        if need_w and Fn._direct(wq_, bq_, wk_, bk_, wv_, bv_):
+            # persistent .grad buffers: weight and bias gradients are accumulated straight into them
+            for wp, bp, off, n in parts:
+                K.conv_wgrad(x, dqkv, wp.grad, (1, 1), n, C_, dy_col=off, dbias=bp.grad)
+            return dx, None, None, None, None, None, None, None, None, None
+        outs = []
         db = torch.zeros(spec.cout, dtype=torch.float32, device=x.device) if need_w else None
-        for w, off, n in ((wq, 0, dq), (wk, dqp, dq), (wv, 2 * dqp, C_)):
+        for w, _, off, n in parts:
             if need_w:
                 dw = torch.zeros_like(w)
                 K.conv_wgrad(x, dqkv, dw, (1, 1), n, C_, dy_col=off, dbias=db[off:off + n])

@@ -84,6 +84,8 @@ def _direct(*params):
     for p in params:
         if p is None:
             continue
+        if not p.is_leaf:                 # (a detached view of a frozen weight: reading .grad of a non-leaf only draws a warning)
+            return False
         g = getattr(p, "grad", None)
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not p.requires_grad:
             return False
@@ -177,11 +179,23 @@ class ConvSpec:
         self.pack = None
 
 
+class GradSlot:
+    """Hand-over of one branch's input gradient to the other branch of a two-consumer tensor (x feeds the main branch AND the
+    1x1 shortcut of a residual block, GResBlock.py:50,70-73): the main branch's backward leaves its dx here instead of returning
+    it, the shortcut conv's backward adds it in the epilogue of its backward-data conv (`res`) and returns the SUM -- the
+    autograd engine would otherwise add the two gradients with a three-pass elementwise kernel.  The shortcut conv returns a
+    0-element token that the main branch takes as an input, so the engine cannot run the shortcut's backward first."""
+
+    def __init__(self):
+        self.dx = None
+
+
 class Conv(Function):
-    """y = act(conv(x; w / sigma) + b [+ res])        (spec.pack is filled by the caller)"""
+    """y = act(conv(x; w / sigma) + b [+ res])        (spec.pack is filled by the caller)
+    slot (a GradSlot): this conv is the shortcut branch -> returns (y, token) and adds slot.dx to its input gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, spec):
+    def forward(ctx, x, w, b, res, spec, slot=None):
         pk = spec.pack
         # a residual at half the output size is read through a nearest x2 upsample (the generator's 1x1 shortcut runs before
         # its upsample: GResBlock.py:72-73 commute exactly)
@@ -192,10 +206,13 @@ class Conv(Function):
         ctx.has_res, ctx.res_up2 = res is not None, ru
         ctx.params = (w, b)                      # the Parameter objects themselves (their .grad buffers)
         ctx.save_for_backward(x, w, y if spec.act != L.ACT_NONE else None)
+        ctx.slot = slot
+        if slot is not None:
+            return y, x.new_empty(0)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtok=None):
         x, w, y = ctx.saved_tensors
         spec, pk = ctx.spec, ctx.pk
         dy = dy.contiguous()
@@ -207,7 +224,11 @@ class Conv(Function):
                 dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, wq=lambda: pk.fragment_major("wd"))
                 dx = K.pool(dx, 1, scale=1.0, mask=x if spec.relu_in else None)      # transpose of nearest x2 (+ ReLU mask)
             else:
-                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None,
+                partner = None
+                if ctx.slot is not None:                  # the other branch's gradient of the same x: summed in the epilogue
+                    partner, ctx.slot.dx = ctx.slot.dx, None
+                    assert not spec.relu_in
+                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None, res=partner,
                                     wq=lambda: pk.fragment_major("wd"))
         wp, bp = ctx.params
         if ctx.needs_input_grad[1] and _direct(wp, bp if ctx.needs_input_grad[2] else None):
@@ -217,8 +238,9 @@ class Conv(Function):
 
             def wgrad():
                 if spec.sn is not None:
-                    G = torch.zeros_like(w)
-                    K.conv_wgrad(x, dy, G, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp)
+                    G = torch.empty_like(w)               # written, not accumulated (`overwrite`): no zero fill
+                    K.conv_wgrad(x, dy, G, spec.ksize, spec.cout, spec.cin, up2=spec.up2, relu_in=spec.relu_in, dbias=dbp,
+                                 overwrite=True)
                     u, v = spec.sn        # CURRENT u / v on purpose (reference quirk 7): no forward runs before the join
                     K.sn_backward(G, w, u, v, sigma, out=wp.grad)
                 else:
@@ -239,7 +261,7 @@ class Conv(Function):
         dres = None
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = K.pool(dy, 1, scale=1.0) if ctx.res_up2 else dy          # transpose of nearest x2: 2 x 2 sums
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None
 
 
 class Pool(Function):
@@ -261,13 +283,20 @@ class LinearF32(Function):
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
+        ctx.params = (W, b)
         return K.linear_forward(x.contiguous(), W, b)
 
     @staticmethod
     def backward(ctx, g):
         x, W = ctx.saved_tensors
-        din, dW, db = K.linear_backward(g.contiguous(), x.contiguous(), W, ctx.needs_input_grad[0],
-                                        ctx.needs_input_grad[1], ctx.has_bias)
+        Wp, bp = ctx.params
+        need_in, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_w and _direct(Wp, bp if ctx.has_bias else None):
+            # persistent .grad buffers: the kernels accumulate straight into them (no zero fill, no autograd add per parameter)
+            din = K.linear_backward(g.contiguous(), x.contiguous(), W, need_in, True, ctx.has_bias,
+                                    dW=Wp.grad, db=bp.grad if ctx.has_bias else None)[0]
+            return din, None, None
+        din, dW, db = K.linear_backward(g.contiguous(), x.contiguous(), W, need_in, need_w, ctx.has_bias)
         return din, dW, db
 
 
@@ -276,11 +305,15 @@ class Embedding(Function):
     def forward(ctx, W, idx32):
         ctx.save_for_backward(idx32)
         ctx.rows = W.shape[0]
+        ctx.param = W
         return K.row_copy(W, idx32, idx32.numel(), W.shape[1], scatter=False)
 
     @staticmethod
     def backward(ctx, g):
         (idx32,) = ctx.saved_tensors
+        if _direct(ctx.param):
+            K.embedding_backward(g.contiguous(), idx32, ctx.rows, dW=ctx.param.grad)
+            return None, None
         return K.embedding_backward(g.contiguous(), idx32, ctx.rows), None
 
 
@@ -289,13 +322,16 @@ class CondBatchNorm(Function):
     """y = relu?(gb[s][:C] * bn(x) + gb[s][C:]),  s = samp[frame]     Normalization.py:78-88"""
 
     @staticmethod
-    def forward(ctx, x, gb, samp, C_real, relu, training, run_mean, run_var, eps, momentum, replicas=None):
+    def forward(ctx, x, gb, samp, C_real, relu, training, run_mean, run_var, eps, momentum, replicas=None, sums=None, tok=None,
+                slot=None):
         """replicas: None (per-replica statistics = nn.DataParallel, trainer.py:357) or (world, all_reduce_sum_) for
-        cross-replica batch norm (Generator.py:57 TODO): statistics and their backward sums span the global batch."""
-        mean, rstd = K.bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas if training else None)
+        cross-replica batch norm (Generator.py:57 TODO): statistics and their backward sums span the global batch.
+        sums: the module's persistent zeroed statistics workspace (kern.bn_stats)."""
+        mean, rstd = K.bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas if training else None, sums)
         y = K.cbn_apply(x, C_real, mean, rstd, gb, samp, relu)
         ctx.save_for_backward(x, gb, samp, mean, rstd)      # (not y: the backward re-evaluates the ReLU mask from x)
         ctx.C_real, ctx.relu, ctx.training, ctx.replicas = C_real, relu, training, replicas
+        ctx.slot = slot if tok is not None else None       # (tok: the shortcut conv's token, see GradSlot)
         return y
 
     @staticmethod
@@ -304,7 +340,9 @@ class CondBatchNorm(Function):
         if not ctx.training:
             raise RuntimeError("CondBatchNorm backward is implemented for training mode only")
         dx, dgb = K.cbn_backward(g.contiguous(), None, x, ctx.C_real, mean, rstd, gb, samp, ctx.relu, ctx.replicas)
-        return dx, dgb, None, None, None, None, None, None, None, None, None
+        if ctx.slot is not None and ctx.needs_input_grad[0]:
+            ctx.slot.dx, dx = dx, None                     # picked up (and added) by the shortcut conv's backward
+        return dx, dgb, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------ ConvGRU layer
@@ -452,6 +490,7 @@ class SelfAttention2d(Function):
         N = x.shape[1] * x.shape[2]
         koff = K.pad8(dq)
         voff = 2 * koff
+        ctx.gamma_param = gamma
         y = torch.zeros_like(x) if x.shape[-1] != C_real else torch.empty_like(x)
         att = torch.zeros_like(x)
         A = torch.empty(F_, N, N, dtype=torch.float32, device=x.device)
@@ -470,11 +509,12 @@ class SelfAttention2d(Function):
         F_ = dy.shape[0]
         dqkv = torch.zeros_like(qkv)
         dS = torch.empty_like(A)
-        dgamma = torch.zeros(1, dtype=torch.float32, device=dy.device)
+        direct = ctx.needs_input_grad[2] and _direct(ctx.gamma_param)       # the kernel ADDS into dgamma: persistent .grad taken as is
+        dgamma = ctx.gamma_param.grad if direct else torch.zeros(1, dtype=torch.float32, device=dy.device)
         L.check(L.lib().dvd_attention_backward(L.dt(dy), L.ptr(qkv), qkv.shape[-1], dq, koff, voff, L.ptr(dy),
                                                dy.shape[-1], C_real, L.ptr(gamma), L.ptr(att), L.ptr(A), L.ptr(dS),
                                                L.ptr(dqkv), L.ptr(dgamma), C.c_longlong(F_), N, L.stream()))
-        return dy, dqkv, dgamma, None, None
+        return dy, dqkv, (None if direct else dgamma), None, None
 
 
 class MaxPool3d(Function):
@@ -600,6 +640,7 @@ class ProjectionHead(Function):
                                           L.ptr(cls32), L.ptr(out), C.c_longlong(F_), C_real, L.stream()))
         ctx.save_for_backward(feat, hsum, w_lin, w_emb, cls32, s_l, s_e)
         ctx.sn = (sn_lin, sn_emb)
+        ctx.params = (w_lin, b_lin, w_emb)
         ctx.meta = (F_, P, C_real)
         return out
 
@@ -611,10 +652,11 @@ class ProjectionHead(Function):
         lib = L.lib()
         dout = dout.contiguous()
         need_w = ctx.needs_input_grad[1]
+        direct = need_w and _direct(*ctx.params)
         dh = torch.empty_like(hsum)
         g_lin = torch.zeros_like(w_lin) if need_w else None
         g_emb = torch.zeros_like(w_emb) if need_w else None
-        g_b = torch.zeros(1, dtype=torch.float32, device=feat.device) if need_w else None
+        g_b = (ctx.params[1].grad if direct else torch.zeros(1, dtype=torch.float32, device=feat.device)) if need_w else None
         L.check(lib.dvd_proj_head_backward(L.ptr(dout), L.ptr(hsum), L.ptr(w_lin), L.ptr(s_l), L.ptr(w_emb), L.ptr(s_e),
                                            L.ptr(cls32), L.ptr(dh), L.ptr(g_lin), L.ptr(g_emb), L.ptr(g_b),
                                            C.c_longlong(F_), C_real, L.stream()))
@@ -624,6 +666,10 @@ class ProjectionHead(Function):
             L.check(lib.dvd_relu_spatial_sum_backward(L.dt(feat), L.ptr(dh), L.ptr(feat), L.ptr(dfeat), C.c_longlong(F_),
                                                       P, C_real, feat.shape[-1], L.stream()))
         dwl = dwe = None
+        if direct:                 # spectral-norm backward adds straight into the persistent .grad buffers
+            K.sn_backward(g_lin, w_lin, sn_lin[0], sn_lin[1], s_l, out=ctx.params[0].grad)
+            K.sn_backward(g_emb, w_emb, sn_emb[0], sn_emb[1], s_e, out=ctx.params[2].grad)
+            return dfeat, None, None, None, None, None, None, None
         if need_w:
             dwl = K.sn_backward(g_lin, w_lin, sn_lin[0], sn_lin[1], s_l)
             dwe = K.sn_backward(g_emb, w_emb, sn_emb[0], sn_emb[1], s_e)

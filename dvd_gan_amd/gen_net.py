@@ -80,12 +80,19 @@ class GResBlock(nn.Module):
 
     def run(self, x, cond, samp):
         up = self.upsample_factor != 1
-        a1 = self.CBNorm1(x, cond, samp, relu=True)
+        # shortcut (GResBlock.py:71-73: upsample, then the 1x1 conv): a 1x1 conv commutes with a nearest upsample value for
+        # value, so it runs on the SMALL grid (a quarter of the rows) and conv1's epilogue reads it through the upsample.
+        # x feeds both branches: the shortcut's backward-data conv adds the main branch's input gradient in its epilogue
+        # (functional.GradSlot) instead of leaving the sum to an elementwise pass of the autograd engine.
+        lowres = not up or _SC_LOWRES
+        slot = Fn.GradSlot() if (lowres and torch.is_grad_enabled() and x.requires_grad) else None
+        skip = self.conv_sc(x, up2=up and not _SC_LOWRES, slot=slot)
+        tok = None
+        if slot is not None:
+            skip, tok = skip
+        a1 = self.CBNorm1(x, cond, samp, relu=True, tok=tok, slot=slot)
         c0 = self.conv0(a1, up2=up)
         a2 = self.CBNorm2(c0, cond, samp, relu=True)
-        # shortcut (GResBlock.py:71-73: upsample, then the 1x1 conv): a 1x1 conv commutes with a nearest upsample value for
-        # value, so it runs on the SMALL grid (a quarter of the rows) and conv1's epilogue reads it through the upsample
-        skip = self.conv_sc(x, up2=up and not _SC_LOWRES)
         return self.conv1(a2, res=skip)
 
 
@@ -133,6 +140,7 @@ class Generator(nn.Module):
                 self.self_attn = SelfAttention(c8, compute_dtype)
             if sep_attn:
                 self.sep_attn = SeparableAttn(c4, compute_dtype)
+        self._nbt_flat = None                       # the 16 `bn.num_batches_tracked` counters as views of ONE tensor (see _count_batches)
         self.dp_global = False                      # data-parallel "global" mode: conditions gathered over the ranks
         self.dp_hooks = False                       # data-parallel trainer sets it: stage-boundary gradient hooks
         self.grad_ready_hook = None                 # callable(first finished module index), armed around backward
@@ -149,9 +157,27 @@ class Generator(nn.Module):
         finally:
             clear_spectral_norm(sn)
 
+    def _count_batches(self, dev):
+        """BatchNorm2d's `num_batches_tracked += 1` of all sixteen conditional batch norms (Normalization.py:72, train mode) as ONE
+        launch: the counters are re-homed as 0-d views of one int64 tensor (state_dict keys and values unchanged; `.to()` / a
+        deep copy replace the buffers, which is noticed by address and repaired here)."""
+        mods = [m for m in self.modules() if isinstance(m, ConditionalNorm)]
+        flat = self._nbt_flat
+        ok = flat is not None and flat.device == dev and flat.numel() == len(mods) and all(
+            m.bn.num_batches_tracked.data_ptr() == flat[i].data_ptr() and not m.count_batches for i, m in enumerate(mods))
+        if not ok:
+            flat = torch.stack([m.bn.num_batches_tracked.detach().reshape(()).to(dev) for m in mods]).clone()
+            for i, m in enumerate(mods):
+                m.bn._buffers["num_batches_tracked"] = flat[i]
+                m.count_batches = False
+            self._nbt_flat = flat
+        flat += 1
+
     def _forward(self, x, class_id, hidden=None):
         B, T = x.shape[0], self.n_frames
         dev = x.device
+        if self.training:
+            self._count_batches(dev)
         class_emb = Fn.Embedding.apply(self.embedding.weight, class_id.to(torch.int32))
         zc = torch.cat([x, class_emb], 1)
         y = Fn.LinearF32.apply(zc, self.affine_transfrom.weight, self.affine_transfrom.bias)

@@ -172,7 +172,7 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
 
 
 def conv_wgrad(x, dy, dw, ksize, cout, cin_real, *, up2=False, relu_in=False, msplit=0, dy_col=0,
-               dw_ci_off=0, dw_ci_tot=None, frames=None, x_row0=0, dy_row0=0, dbias=None):
+               dw_ci_off=0, dw_ci_tot=None, frames=None, x_row0=0, dy_row0=0, dbias=None, overwrite=False):
     """dw[co][dw_ci_off + ci][*k] += sum_rows dy[row][dy_col + co] * x[shifted row][ci]   (fp32 atomics)
     dw: fp32 master-layout tensor [cout][dw_ci_tot][*k].  x / dy may be row-sliced views given by
     (tensor, first frame): `frames` frames starting at frame x_row0 of x and dy_row0 of dy."""
@@ -196,6 +196,7 @@ def conv_wgrad(x, dy, dw, ksize, cout, cin_real, *, up2=False, relu_in=False, ms
     d.dy = dy.data_ptr() + (dy_row0 * T * H * W * dy.shape[-1] + dy_col) * esz
     d.dw = dw.data_ptr() + dw_ci_off * ntaps * 4
     d.dbias = dbias.data_ptr() if dbias is not None else None      # fp32 [cout], accumulated
+    d.overwrite = int(overwrite)                                    # dw = result (dense dw only): `dw` may be torch.empty
     nws = L.lib().dvd_conv_wgrad_ws_floats(C.byref(d))              # >0: deterministic two-phase reduction
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws > 0 else None
     d.ws = ws.data_ptr() if ws is not None else None
@@ -212,23 +213,33 @@ def _f(v):
     return C.c_float(float(v))
 
 
-def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas=None):
+def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas=None, sums=None):
     """-> (mean, rstd) fp32 [C_real]; updates the running buffers in training mode.
+    sums: optional PERSISTENT zeroed fp64 workspace [BN_NREP * 2 * C_real] of the caller -- dvd_bn_finalize leaves it zeroed
+    again, so no fill is launched per call.
     replicas: None, or (world, all_reduce_sum_) for cross-replica statistics -- the [BN_NREP][2C] fp64 sums are added over the
     replicas before mean / variance are formed from world * rows samples."""
     ld = x.shape[-1]
     rows = x.numel() // ld
     mean = torch.empty(C_real, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    sums = None
-    if training:
-        sums = torch.zeros(L.BN_NREP * 2 * C_real, dtype=torch.float64, device=x.device)
-        L.check(L.lib().dvd_bn_stats(L.dt(x), L.ptr(x), _ll(rows), C_real, ld, L.ptr(sums), L.stream()))
-        if replicas is not None:
-            replicas[1](sums)
-            rows *= replicas[0]
-    L.check(L.lib().dvd_bn_finalize(L.ptr(sums), _ll(rows), C_real, _f(eps), _f(momentum), int(training),
-                                    L.ptr(mean), L.ptr(rstd), L.ptr(run_mean), L.ptr(run_var), L.stream()))
+    keep = sums is not None and training
+    if not keep:
+        sums = None
+    try:
+        if training:
+            if sums is None:
+                sums = torch.zeros(L.BN_NREP * 2 * C_real, dtype=torch.float64, device=x.device)
+            L.check(L.lib().dvd_bn_stats(L.dt(x), L.ptr(x), _ll(rows), C_real, ld, L.ptr(sums), L.stream()))
+            if replicas is not None:
+                replicas[1](sums)
+                rows *= replicas[0]
+        L.check(L.lib().dvd_bn_finalize(L.ptr(sums), _ll(rows), C_real, _f(eps), _f(momentum), int(training),
+                                        L.ptr(mean), L.ptr(rstd), L.ptr(run_mean), L.ptr(run_var), int(keep), L.stream()))
+    except Exception:
+        if keep:
+            sums.zero_()                  # a failed call must not leave a dirty workspace behind
+        raise
     return mean, rstd
 
 
@@ -372,19 +383,22 @@ def linear_forward(inp, W, bias):
     return out
 
 
-def linear_backward(dout, inp, W, need_in, need_w, has_bias):
+def linear_backward(dout, inp, W, need_in, need_w, has_bias, dW=None, db=None):
+    """dW / db given: fp32 buffers the kernels ADD into (persistent .grad); else fresh zero tensors."""
     B, K = inp.shape
     J = W.shape[0]
     din = torch.empty_like(inp) if need_in else None
-    dW = torch.zeros_like(W) if need_w else None
-    db = torch.zeros(J, dtype=torch.float32, device=inp.device) if (need_w and has_bias) else None
+    if dW is None:
+        dW = torch.zeros_like(W) if need_w else None
+        db = torch.zeros(J, dtype=torch.float32, device=inp.device) if (need_w and has_bias) else None
     L.check(L.lib().dvd_linear_backward(L.ptr(dout), L.ptr(inp), L.ptr(W), L.ptr(din), 0, L.ptr(dW), L.ptr(db), B, K, J,
                                         L.stream()))
     return din, dW, db
 
 
-def embedding_backward(dout, idx, nrows):
-    dW = torch.zeros(nrows, dout.shape[1], dtype=torch.float32, device=dout.device)
+def embedding_backward(dout, idx, nrows, dW=None):
+    if dW is None:
+        dW = torch.zeros(nrows, dout.shape[1], dtype=torch.float32, device=dout.device)
     L.check(L.lib().dvd_embedding_backward(L.ptr(dout), L.ptr(idx), L.ptr(dW), _ll(dout.shape[0]), dout.shape[1], L.stream()))
     return dW
 

@@ -27,7 +27,8 @@ class WgradDesc(C.Structure):
                 ("ldy", C.c_int), ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("up2", C.c_int),
                 ("relu_in", C.c_int), ("msplit", C.c_int),
                 ("s_co", C.c_longlong), ("s_ci", C.c_longlong), ("s_tap", C.c_longlong),
-                ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("ws", C.c_void_p)]
+                ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("ws", C.c_void_p),
+                ("overwrite", C.c_int)]
 
 
 def lib():

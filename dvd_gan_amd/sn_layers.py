@@ -89,7 +89,7 @@ class SpectralNormConv(nn.Module):
         K.sn_power_iter(m.weight_bar.data, m.weight_u.data, m.weight_v.data, sigma)
         pack.fill(m.weight_bar.data, sigma)
 
-    def forward(self, x, *, res=None, act=L.ACT_NONE, up2=False, relu_in=False):
+    def forward(self, x, *, res=None, act=L.ACT_NONE, up2=False, relu_in=False, slot=None):
         m = self.module
         if self._pre is not None:          # prepared by prefetch_spectral_norm on the side stream
             sigma, pack, ev = self._pre
@@ -103,7 +103,7 @@ class SpectralNormConv(nn.Module):
         spec.sigma = sigma
         spec.pack = pack
         w, b = (m.weight_bar, m.bias) if self.train_weights else (m.weight_bar.detach(), m.bias.detach())
-        return Fn.Conv.apply(x, w, b, res, spec)
+        return Fn.Conv.apply(x, w, b, res, spec, slot)
 
 
 _SN_STREAMS = {}
@@ -203,11 +203,15 @@ class ConditionalNorm(nn.Module):
         self.embed.weight = nn.Parameter(w)
         self.embed.bias = nn.Parameter(b)
         self.replicas = None               # (world, all_reduce_sum_) when batch statistics span all replicas
+        self._sums = None                  # persistent fp64 workspace of the statistics kernel (left zeroed by dvd_bn_finalize)
+        self.count_batches = True          # False: a caller (the Generator) advances num_batches_tracked for all layers at once
 
-    def forward(self, x, cond, samp, relu=True):
-        """x: channels-last [frames, H, W, Cp]; cond: fp32 [B, n_condition]; samp: int32 [frames]."""
+    def forward(self, x, cond, samp, relu=True, tok=None, slot=None):
+        """x: channels-last [frames, H, W, Cp]; cond: fp32 [B, n_condition]; samp: int32 [frames].  tok / slot: functional.GradSlot."""
         gb = Fn.LinearF32.apply(cond, self.embed.weight, self.embed.bias)
-        if self.training:
+        if self.training and self.count_batches:
             self.bn.num_batches_tracked += 1
+        if self._sums is None or self._sums.device != x.device:
+            self._sums = torch.zeros(L.BN_NREP * 2 * self.in_channel, dtype=torch.float64, device=x.device)
         return Fn.CondBatchNorm.apply(x, gb, samp, self.in_channel, relu, self.training, self.bn.running_mean,
-                                      self.bn.running_var, 1e-5, 0.1, self.replicas)
+                                      self.bn.running_var, 1e-5, 0.1, self.replicas, self._sums, tok, slot)

@@ -120,6 +120,7 @@ typedef struct {
     float* ws;                 /* optional workspace of dvd_conv_wgrad_ws_floats(d) floats: row slices write
                                   their partial tiles there with plain stores and a second kernel reduces
                                   them into dw (deterministic, no atomics).  NULL = fp32 atomics on dw      */
+    int overwrite;             /* 1: dw = result instead of dw += result (dense [co][ci][tap] dw only): no zero fill by the caller */
 } dvd_wgrad_desc;
 int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream);
 long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d);   /* 0 = no workspace needed (single slice) */
@@ -195,8 +196,9 @@ int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps);
  * ---------------------------------------------------------------------------------------- */
 #define DVD_BN_NREP 16      /* copies of the [2C] sums the statistics kernel spreads its atomics over (dvd_bn_finalize adds them up) */
 int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int ld, double* sums /*[DVD_BN_NREP][2C], zeroed*/, void* stream);
-int dvd_bn_finalize(const double* sums, long long rows, int C, float eps, float momentum, int training,
-                    float* mean, float* rstd, float* run_mean, float* run_var, void* stream);
+int dvd_bn_finalize(double* sums /* read, then reset to zero when `rezero`: a persistent workspace needs no fill per call */,
+                    long long rows, int C, float eps, float momentum, int training,
+                    float* mean, float* rstd, float* run_mean, float* run_var, int rezero, void* stream);
 int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames, int P, int C, int ld, const float* mean,
                   const float* rstd, const float* gb, const int* samp, int relu, void* stream);
 /* g: gradient wrt the (ReLU'd) output, x: CBN input.  Produces dx and accumulates dgb[B][2C] (zeroed by the caller);

@@ -58,3 +58,18 @@ for s, e, st, wg, n in rows:
 print("small main-stream launches:")
 for k, v in sorted(sm.items(), key=lambda kv: -kv[1][1])[:12]:
     print("  %6d %8.2f ms  %s" % (v[0], v[1], k))
+# idle time by what runs around it: the kernel that ended before a gap of the main stream (host-bound stretches show up as many
+# gaps after tiny kernels)
+gaps = collections.defaultdict(lambda: [0, 0.0])
+mrows = sorted(r for r in rows)
+busy_until = mrows[0][1]
+prev = mrows[0][4]
+for s, e, st, wg, n in mrows[1:]:
+    if s > busy_until:
+        k = prev.split("(")[0][:60]
+        gaps[k][0] += 1; gaps[k][1] += (s - busy_until) / 1e6
+    if e > busy_until:
+        busy_until, prev = e, n
+print("GPU-idle gaps (no kernel on any stream), by the kernel that ran before the gap:")
+for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
+    print("  %6d %8.2f ms  %s" % (v[0], v[1], k))
