@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     constexpr int NWAVE = WM * NH, NTt = NWAVE * 64, BMc = WM * 64, BNc = NH * 32;
     constexpr int RSA = BMc * 2 + 64;
     constexpr int TA_BYTES = 32 * RSA;
-    constexpr int XROWS = 48, XHALF = XROWS * 64, TB_BYTES = NH * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows
+    constexpr int XROWS = KW == 5 ? 64 : 48, XHALF = XROWS * 64, TB_BYTES = NH * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows; W = 4: 8 lines x 8 (6) rows
     constexpr int NS = 2;      // 32-pixel sub-steps per barrier (3x3: 0.72 -> 0.80 PF/s, 5x5: +3 %; three sub-steps cost occupancy)
     constexpr int SUB = TA_BYTES + TB_BYTES, STAGE = NS * SUB;
     constexpr int EPIB = NWAVE * 32 * 32 * 4;
@@ -1817,17 +1817,20 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
         }
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
-            const int yy = y + xseg[i] + dyl;                       // output line the tap row looks at
+            // output line the tap row looks at.  A 32-pixel step of 4 x 4 frames spans TWO frames (8 lines): line y + xseg of the
+            // step is line (.. & (H-1)) of frame (.. >> logH) counted from the step's first frame
+            const int lf = y + xseg[i], fo = lf >> p.logH;
+            const int yy = (lf & (p.H - 1)) + dyl;
             bool ok = xcv[i] && tok && (unsigned)yy < (unsigned)p.H;
             int row;
             if (UP2) {
                 const int xin = (x0 >> 1) - cpad + xj[i];
                 ok = ok && (unsigned)xin < (unsigned)p.Win;
-                row = (mk >> (p.logW + p.logH)) * (p.Hin * p.Win) + (yy >> 1) * p.Win + xin;
+                row = ((mk >> (p.logW + p.logH)) + fo) * (p.Hin * p.Win) + (yy >> 1) * p.Win + xin;
             } else {
                 const int xx = x0 + xj[i] - pad;
                 ok = ok && (unsigned)xx < (unsigned)p.W;
-                row = frow0 + (yy << p.logW) + xx;
+                row = frow0 + (fo << (p.logW + p.logH)) + (yy << p.logW) + xx;
             }
             const unsigned off = ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i] : 0xffffffffu;
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
@@ -2381,8 +2384,10 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         else if (d->Cin_real >= 192) tb = 4;
     }
     static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
-    mode = (use_row && pow2 && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) && d->W >= 8 &&
-            (d->H * d->W) % 32 == 0) ? 1 : 0;
+    mode = (use_row && pow2 && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) &&
+            ((d->W >= 8 && (d->H * d->W) % 32 == 0) ||
+             // 4 x 4 frames (round 4): a 32-pixel step = two whole frames
+             (d->W == 4 && d->H == 4 && d->kt == 1 && d->T == 1 && !d->up2 && (d->frames & 1) == 0))) ? 1 : 0;
     if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
         const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
         static const int force_wm = getenv("DVD_WGR_WM") ? atoi(getenv("DVD_WGR_WM")) : 0;

@@ -74,6 +74,9 @@ CASES = [
     (128, 16, 24, (8, 8), (3, 3), False, True),          # one pixel per tile
     (32, 24, 264, (8, 8), (5, 5), False, False),         # 4 pixels x 32 frames, three N tiles
     (256, 16, 264, (4, 4), (5, 5), False, False),        # 8-wave 256 x 256 tile
+    # filter-row weight-gradient kernel on 4 x 4 frames (round 4): a 32-pixel step = two whole frames
+    (6, 72, 200, (4, 4), (3, 3), False, True),
+    (10, 136, 72, (4, 4), (5, 5), False, False),
     # extents that are not powers of two (latent_dim 3 / 6: 6, 12, 24, 48, 96 pixels): division indexing, tap-by-tap kernels
     (3, 16, 24, (6, 6), (3, 3), False, False),
     (2, 24, 40, (12, 12), (5, 5), False, True),
@@ -208,3 +211,46 @@ def test_f32_to_bf16_is_round_to_nearest_even():
     nan = torch.isnan(want.float())
     assert bool((torch.isnan(got.float()) == nan).all())
     assert torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan])
+
+
+DEV = "cuda"
+
+
+GB_CASES = [  # frames, S, Cin, Cout, k, up2, relu_in, nsplit
+    (64, 32, 512, 256, 5, 0, 0, 1), (64, 16, 1024, 512, 5, 0, 0, 2), (256, 32, 256, 384, 5, 0, 0, 1),      # 256 x 128 tile
+    (64, 32, 128, 128, 3, 0, 0, 1), (64, 16, 256, 256, 3, 0, 0, 2),                                          # 128 x 128 tile
+    (512, 64, 64, 64, 3, 0, 0, 1), (512, 64, 8, 64, 3, 0, 0, 1), (512, 64, 128, 64, 3, 1, 1, 1),             # 256 x 64 (thin) tile
+    (256, 32, 256, 128, 3, 1, 1, 1), (256, 32, 128, 128, 3, 0, 1, 1),                                        # x2 fold, ReLU on fragments
+    (64, 8, 512, 1024, 5, 0, 0, 4), (64, 8, 256, 512, 3, 0, 0, 4), (3072, 8, 256, 256, 3, 0, 1, 1),         # whole-frame footprints, 8 x 8
+    (64, 4, 512, 1024, 5, 0, 0, 8), (3072, 4, 256, 768, 3, 0, 0, 1), (61, 8, 64, 96, 3, 0, 0, 1), (13, 4, 40, 72, 5, 0, 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", GB_CASES)
+def test_weights_from_l2_kernels_equal_the_lds_staged_kernels(case):
+    """conv_halo_gb_kernel / conv_halo_gbs_kernel (weight fragments read from L2 in fragment-major order, no per-tap barrier) keep
+    the K order of conv_halo_kernel / conv_igemm_kernel: the outputs must be BIT-identical, on every tile shape, with the nearest
+    x2 fold, ReLU on the fragments, split-K slabs, ragged frame counts and channel counts -- repeated, because a missing
+    hand-over would show as a rare difference."""
+    from dvd_gan_amd import kern as K
+    F_, S, Cin, Cout, k, up2, relu, ns = case
+    torch.manual_seed(F_ + S + Cin + Cout)
+    Sin = S // 2 if up2 else S
+    x = torch.randn(F_, Sin, Sin, K.pad8(Cin), device=DEV).to(torch.bfloat16)
+    if K.pad8(Cin) != Cin:
+        x[..., Cin:] = 0
+    pk = K.PackedConv(torch.bfloat16, Cout, Cin, (k, k), DEV).fill(torch.randn(Cout, Cin, k, k, device=DEV) * 0.05)
+    wq = pk.fragment_major("wf")
+    kw = dict(up2=bool(up2), relu_in=bool(relu), nsplit=ns, slabs=ns > 1)
+    assert K.wants_fragment_major(torch.bfloat16, F_, S, S, K.pad8(Cin), Cout, k, ns) or up2
+    ref = K.conv_forward(x, pk.wf, (k, k), Cout, **kw).clone()
+    for _ in range(5):
+        assert torch.equal(ref, K.conv_forward(x, pk.wf, (k, k), Cout, wq=wq, **kw))
+
+
+def test_weights_from_l2_kernel_3d_taps():
+    from dvd_gan_amd import kern as K
+    x = torch.randn(16, 12, 32, 32, 64, device=DEV).to(torch.bfloat16)
+    pk = K.PackedConv(torch.bfloat16, 64, 64, (3, 3, 3), DEV).fill(torch.randn(64, 64, 3, 3, 3, device=DEV) * 0.05)
+    ref = K.conv_forward(x, pk.wf, (3, 3, 3), 64).clone()
+    assert torch.equal(ref, K.conv_forward(x, pk.wf, (3, 3, 3), 64, wq=pk.fragment_major("wf")))

@@ -42,6 +42,10 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (3072, 64, 64, 64, 3, False),     # 30: thin output (256 x 64 tile): last GResBlock conv1
     (3072, 64, 128, 64, 3, False),    # 31
     (512, 64, 64, 64, 3, False),      # 32: D_s pre_conv.2
+    (3008, 4, 512, 512, 5, False),    # 33..36: weight gradients on 4 x 4 frames (gru0.l1 h-part / x-part, gru0.l0, GResBlock)
+    (3072, 4, 256, 1536, 5, False),
+    (3008, 4, 256, 256, 3, False),
+    (3072, 4, 256, 256, 3, False),
 ]
 
 
