@@ -132,3 +132,17 @@ def test_four_rank_bucketed_exchange():
     out = mgr.dict()
     mp.spawn(_worker4, args=(4, _free_port(), out), nprocs=4, join=True)
     assert sorted(out.keys()) == [0, 1, 2, 3]
+
+
+def test_rccl_group_is_created_with_a_high_priority_stream():
+    """RCCL's kernels run on ProcessGroupNCCL's own stream; it is high-priority only when the group is created with
+    Options(is_high_priority_stream=True).  dist.init_from_env passes this object as pg_options for the nccl backend."""
+    import inspect
+    from dvd_gan_amd import dist as D
+    opts = D.nccl_high_priority_options()
+    if opts is None:
+        import pytest
+        pytest.skip("this torch build has no nccl backend")
+    assert opts.is_high_priority_stream is True
+    src = inspect.getsource(D.init_from_env)
+    assert "pg_options" in src and "nccl_high_priority_options" in src

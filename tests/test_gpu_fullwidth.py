@@ -310,6 +310,34 @@ def test_bf16_free_running_step(oracle_run):
     assert res["Ds"]["cos_all"] > 0.999 and res["Dt"]["cos_all"] > 0.999 and res["G"]["cos_all"] > 0.99, res
 
 
+def test_bf16_step_at_128x128_full_width(golden):
+    """BASELINE configs[3]'s per-clip shape in the TIMED mode: one bf16 step at ch=32, T=48, 128x128, 600 classes, B=1 against the
+    reference's own numbers (fixture F16; no oracle run: the reference takes four minutes per step at this size).  Bounds as for
+    the 64x64 shape: six losses within 1e-2; per network, the stored heads of the named gradients as one vector
+    cosine >= 0.999 (D_s, D_t) / >= 0.99 (G), and the |grad| checksums of all parameters as one vector within 2e-2 relative."""
+    g = golden("f16_full_width_128")
+    tr = make_trainer(g, torch.bfloat16)
+    snaps = snapshot_hip_grads(tr)
+    losses = [float(v.detach()) for v in tr.train_step(torch.as_tensor(fixture_real(g, 0)), torch.as_tensor(g["in.labels.0"]),
+                                                      draws_of(g))]
+    res = {"losses": losses, "abs_err": [abs(a - float(b)) for a, b in zip(losses, g["out.losses.0"])]}
+    for tag in ("Ds", "Dt", "G"):
+        named = sub(g, f"grad.0.{tag}")
+        a = torch.cat([snaps[tag][kk].reshape(-1)[:v.size].double().cpu() for kk, v in named.items()])
+        b = torch.cat([torch.as_tensor(v).double().reshape(-1) for v in named.values()])
+        keys = [str(x) for x in g[f"meta.gsum_keys.{tag}"]]
+        got = np.array([float(snaps[tag][kk].double().abs().sum()) for kk in keys])
+        ref = g[f"out.gsum.0.{tag}"]
+        res[tag] = {"cos_named": cosine(a, b), "gsum_rel": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
+                    "cos_each": {kk: cosine(snaps[tag][kk].reshape(-1)[:v.size], v) for kk, v in named.items()}}
+    NUMBERS["bf16.f16_128x128"] = res
+    _dump()
+    np.testing.assert_allclose(losses, g["out.losses.0"], atol=1e-2, rtol=0)
+    assert res["Ds"]["cos_named"] > 0.999 and res["Dt"]["cos_named"] > 0.999 and res["G"]["cos_named"] > 0.99, res
+    for tag in ("Ds", "Dt", "G"):
+        assert res[tag]["gsum_rel"] < 2e-2, (tag, res[tag]["gsum_rel"])
+
+
 @pytest.mark.parametrize("init", ["fixture", "torch_default"])
 def test_sensitivity_of_the_free_running_generator(oracle_run, init):
     """What bounds the generator's end-to-end OUTPUT in bf16 is the network's own conditioning, which depends on the weights:
