@@ -102,10 +102,13 @@ template <> __device__ __forceinline__ float gate_tanh<bf16_t>(float x) {
 // by gru.hip when the recurrent conv needs no split-K.  mode 1: [u|r] conv, mode 2: out-gate conv (forward);
 // mode 3: d(h*r) conv of the backward pass (r, hprev, h32n = fp32 carry, o = dg base), mode 4: carry += conv,
 // mode 5: mode 4 + first half of the next BPTT step (gx = dh_out, u_in = u, hr = o-gate, hprev, o = dg of that step).
+// nsplit > 1 with a gate epilogue (round 4): `slabs` / `tickets` = workspace of the in-launch split-K combine (splitk_combine,
+// conv_igemm.hip): nsplit * tiles * tile floats, one zero-initialised counter per tile (left at zero by every launch).
 struct GruEpi {
     int mode, h, ldg;
     const void* gx; const void* hprev; const float* h32p; const void* u_in;
     void* u; void* r; void* hr; void* o; void* hn; float* h32n;
+    float* slabs; unsigned* tickets;
 };
 extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream);
 

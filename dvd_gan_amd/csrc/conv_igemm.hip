@@ -195,12 +195,94 @@ __device__ __forceinline__ void epi_run(Stage stage, Load load, Compute compute)
     }
 }
 
+// ---------------------------------------------------------------------------- in-launch split-K combine (round 4)
+// A split-K recurrent convolution used to leave ns fp32 slabs [z][M][Cout] for a gate kernel that summed them and applied the
+// ConvGRU gate math: two launches per convolution on a chain of dependent launches.  Here the LAST workgroup of a tile to finish
+// sums the slices and runs the fused gate epilogue itself -- no spinning, nobody waits for anybody:
+//   every slice workgroup   writes its accumulators, in register order, to its slab with write-through (sc1) 16-byte stores
+//                           -> every wave drains vmcnt -> barrier -> lane 0 draws a ticket (relaxed agent-scope fetch_add)
+//   ticket != ns - 1        done
+//   ticket == ns - 1        all other slabs are complete and in memory (their writers drained before drawing): read them with sc1
+//                           loads (they bypass this CU's L1 and this XCD's L2 copy of a previous launch's data), add them in slice
+//                           order, reset the ticket for the next launch on the stream, go on into the gate epilogue.
+// The sum is the same whichever workgroup arrives last: ns == 2 adds the other slab onto the registers (a + b == b + a), ns > 2
+// re-reads all ns slabs, its own included, into zeroed accumulators in slice order.  Slab layout (private to this function):
+// [tile = blockIdx.x][slice][wave][tm][tn][quad][lane] x 16 bytes.  cdna_hip_programming.md section 5 (split-K reduction recipe).
+template <int TM>
+__device__ __forceinline__ bool splitk_combine(const ConvK& p, f32x16 (&acc)[TM][2], float* lds0, int lane, int z) {
+    constexpr unsigned kWaveBytes = TM * 2 * 4 * 1024;
+    constexpr int kSc1 = 16;                          // cache-policy bit 4 on gfx950: sc1
+    const int ns = p.nsplit;
+    const int wave = threadIdx.x >> 6;
+    const unsigned tileBytes = (blockDim.x >> 6) * kWaveBytes;
+    const size_t tile = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((char*)p.g.slabs + tile * ns * (size_t)tileBytes), 0, (unsigned)ns * tileBytes, 0x00020000);
+    const unsigned lo = wave * kWaveBytes + lane * 16;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 v = {__float_as_uint(acc[tm][tn][4 * q]), __float_as_uint(acc[tm][tn][4 * q + 1]),
+                                 __float_as_uint(acc[tm][tn][4 * q + 2]), __float_as_uint(acc[tm][tn][4 * q + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, z * tileBytes + lo + ((tm * 2 + tn) * 4 + q) * 1024, 0, kSc1);
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *reinterpret_cast<volatile unsigned*>(lds0) =
+            __hip_atomic_fetch_add(p.g.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *reinterpret_cast<volatile unsigned*>(lds0);
+    if (ticket != (unsigned)(ns - 1)) return false;
+    __syncthreads();                                   // the word is read before the staging area is written again
+    if (threadIdx.x == 0) __hip_atomic_store(p.g.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int s_begin = 0, s_end = ns;
+    if (ns == 2) { s_begin = z ^ 1; s_end = s_begin + 1; }
+    else {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = zacc;
+    }
+    // groups of 4 loads (one 32 x 32 accumulator block), the next group requested before this one is added: 8 loads per lane in
+    // flight on 32 registers (the scheduling fences keep hipcc from hoisting every load of the unrolled body to the top -- 348
+    // registers in the 256 x 128 kernels).  The group behind the last slab gets an out-of-range offset: zeros, no branch.
+    u32x4 buf[2][4];
+    auto issue = [&](int s, int g, u32x4 (&b)[4]) __attribute__((always_inline)) {
+        const unsigned so = s < s_end ? (unsigned)s * tileBytes : kOOB;      // (the range check sees the vector offset only)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, so + lo + (g * 4 + i) * 1024, 0, kSc1);
+    };
+    issue(s_begin, 0, buf[0]);
+    for (int s = s_begin; s < s_end; ++s) {
+#pragma unroll
+        for (int g = 0; g < 2 * TM; ++g) {
+            if (g + 1 < 2 * TM) issue(s, g + 1, buf[(g + 1) & 1]);
+            else issue(s + 1, 0, buf[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = buf[g & 1][i];
+                f32x16& a = acc[g >> 1][g & 1];
+                a[4 * i] += __uint_as_float(v.x); a[4 * i + 1] += __uint_as_float(v.y);
+                a[4 * i + 2] += __uint_as_float(v.z); a[4 * i + 3] += __uint_as_float(v.w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return true;
+}
+
 // `ep`: the wave's LDS staging block (32 x 64 floats); col: first of this lane's 8 output columns; row0: first row every
 // row of this workgroup's tile is relative to (the buffer descriptors start there, offsets stay 32-bit); relrow(tm, j): this
 // lane's row of round j of sub-tile tm, relative to row0, or a negative number when it lies past M.
 // DEEP: deeper operand pipelines for the gate epilogues (kernels whose accumulators live in the unified register file can spend the
 // registers of already-staged sub-tiles on operands in flight)
-template <typename T, int TM, int DEEP = 0, class RelRow>
+template <typename T, int TM, int DEEP = 0, bool COMBINE = true, class RelRow>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][2], float* ep, int lane, int col, int z,
                                               long long row0, RelRow relrow) {
     constexpr unsigned esz = sizeof(T);
@@ -233,7 +315,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
 #ifdef DVD_EXP_NOEPI           // compile-time measurement variant (tools/build_variant.sh): the epilogue is skipped, results are garbage
     return;
 #endif
-    if (mode == 1) {                // [u|r] = sigmoid(acc + gx);  hr = h_prev * r        (ConvGRU.py:47-49)
+    // split-K with a gate epilogue: only the last slice workgroup of the tile to arrive goes on, holding the full sums
+    if constexpr (COMBINE)
+        if (mode != 0 && p.nsplit > 1 && !splitk_combine<TM>(p, acc, ep - (threadIdx.x >> 6) * (32 * 64), lane, z)) return;
+    if (mode == 1) {              // [u|r] = sigmoid(acc + gx);  hr = h_prev * r        (ConvGRU.py:47-49)
         constexpr int D = kB ? 3 : 1;
         const int h = p.g.h;
         const bool isr = col >= h;
@@ -651,13 +736,14 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     float* ep = reinterpret_cast<float*>(&smem[0][0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     if (p.pm) {          // rows of the tile are scattered over the tensor: offsets from its start (small tensors only, see conv_plan)
-        conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, 0ll, [&](int tm, int j) __attribute__((always_inline)) {
+        conv_epilogue<T, TM, 0, WN == 2>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, 0ll, [&](int tm, int j) __attribute__((always_inline)) {
             const int mp = m0 + wm * (TM * 32) + tm * 32 + j * 8 + erow;
             return mp < p.M ? memrow(mp) : -1;
         });
         return;
     }
-    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (long long)m0, [&](int tm, int j) __attribute__((always_inline)) {
+    // (WN == 2: the 8-wave tile has no registers to spare for the in-launch split-K combine)
+    conv_epilogue<T, TM, 0, WN == 2>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (long long)m0, [&](int tm, int j) __attribute__((always_inline)) {
         const int rr = wm * (TM * 32) + tm * 32 + j * 8 + erow;
         return m0 + rr < p.M ? rr : -1;
     });
@@ -2209,8 +2295,8 @@ extern "C" int dvd_conv_forward(const dvd_conv_desc* d, void* stream) { return d
 // Validates a forward / backward-data request and derives the kernel parameters and the variant that serves it.
 struct ConvPlan { long long M; bool halo, thin, wide, big, smallf; };
 static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan& pl) {
-    if (!d || !d->in || !d->w || (!d->ws && (!d->out || d->nsplit > 1))) return DVD_E_ARG;
-    if (g && (d->ws || d->nsplit > 1 || (g->h & 7))) return DVD_E_ARG;
+    if (!d || !d->in || !d->w || (!d->ws && (!d->out || (d->nsplit > 1 && !g)))) return DVD_E_ARG;
+    if (g && (d->ws || (g->h & 7) || (d->nsplit > 1 && (!g->slabs || !g->tickets)))) return DVD_E_ARG;
     if (d->frames <= 0 || d->T <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Cout <= 0) return DVD_E_ARG;
     int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
     const bool pow2 = logH >= 0 && logW >= 0;
@@ -2252,7 +2338,8 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
                         d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->H == d->W && (d->W == 4 || d->W == 8) &&
                         p.nsplit <= p.kchunks && M < (1ll << 24);
     const bool thin = halo && d->dtype == DVD_BF16 && d->Cout <= 64 && cdiv(M, 256) * (long long)p.nsplit >= 512;
-    const bool wide = !halo && !smallf && d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256;
+    const bool wide = !halo && !smallf && d->dtype == DVD_BF16 && d->Cout >= 256 && (rem256 == 0 || rem256 > 224) && t256 >= 256 &&
+                      !(g && p.nsplit > 1);
     p.tilesN = wide ? (d->Cout + 255) / 256 : thin ? 1 : (d->Cout + BN - 1) / BN;
     p.up2 = d->up2; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     if (g) p.g = *g; else p.g = GruEpi{};

@@ -192,20 +192,21 @@ __global__ void gru_dh0_kernel(const float* carry, const float* ws, int ns, floa
 }
 
 // recurrent conv whose epilogue applies the gate math directly (no split-K, no fp32 slabs)
+// (nsplit > 1: in-launch split-K, the tile's last workgroup to arrive runs the gate epilogue -- g.slabs / g.tickets)
 int conv_fused(int dtype, int B, int H, int W, int k, const void* in, int C, const void* w, const void* wq, int Cout, const GruEpi& g,
-               void* stream) {
+               int nsplit, void* stream) {
     dvd_conv_desc d = {};
     d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = C; d.Cout = Cout; d.ldo = Cout;
-    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.wq = wq; d.out = g.mode == 1 ? g.u : g.hn;   // (`out` itself is not written)
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = nsplit; d.in = in; d.w = w; d.wq = wq; d.out = g.mode == 1 ? g.u : g.hn;   // (`out` itself is not written)
     return dvd_conv_forward_gru(&d, &g, stream);
 }
 
 // backward-data conv of the BPTT whose epilogue folds the result into the carry / gate gradients (modes 3, 4)
 int conv_fused_bwd(int dtype, int B, int H, int W, int k, const void* in, int C, int ldi, const void* w, const void* wq, int Cout,
-                   const GruEpi& g, void* stream) {
+                   const GruEpi& g, int nsplit, void* stream) {
     dvd_conv_desc d = {};
     d.dtype = dtype; d.frames = B; d.T = 1; d.H = H; d.W = W; d.C = C; d.ldi = ldi; d.Cout = Cout; d.ldo = Cout;
-    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = 1; d.in = in; d.w = w; d.wq = wq; d.out = g.h32n;     // `out` itself is not written
+    d.kt = 1; d.kh = k; d.kw = k; d.nsplit = nsplit; d.in = in; d.w = w; d.wq = wq; d.out = g.h32n;     // `out` itself is not written
     return dvd_conv_forward_gru(&d, &g, stream);
 }
 
@@ -258,6 +259,32 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
     return (int)ns;
 }
 
+// Largest split-K factor whose slices are combined inside the launch (by the tile's last workgroup to arrive) instead of by a gate
+// kernel.  Measured per layer (tools/gru_microbench.py, B = 64, us per step forward / backward, same box): at 2 slices the combine is
+// one 64-128 KB slab read and replaces a launch on the chain -- S = 16 layers 102.0 / 106.1 -> 84.3 / 92.1 (3 x 3), 544.5 / 549.3 ->
+// 509.2 / 536.1 (5 x 5); at 4 slices it still gains a little (S = 8, 3 x 3: 50.5 / 53.3 -> 47.6 / 50.9); at 8 the serial read of eight
+// slabs by ONE workgroup per tile costs more than the gate kernel, which spreads the same reads over the whole chip (S = 4:
+// 33.9 / 35.9 -> 37.9 / 39.4, 67.3 / 69.6 -> 72.6 / 80.3).  Fewer, longer slices so that everything combines in-launch lose as well
+// (DVD_NS_CAP = 2: the S = 4 / 8 layers 56.4 -> 70.4 ms over a pass pair).  DVD_GRU_INLAUNCH = 0 (never) ... 8 is an A/B aid.
+static int inlaunch_max() {
+    static const int v = getenv("DVD_GRU_INLAUNCH") ? atoi(getenv("DVD_GRU_INLAUNCH")) : 4;
+    return v;
+}
+
+// floats of dvd_gru_desc.ws: nsplit slabs of whole output tiles (up to 256 rows x 256 columns) for the widest of the three
+// recurrent convolutions of a layer
+extern "C" long long dvd_convgru_ws_floats(int dtype, int B, int H, int W, int hidden, int k) {
+    const long long M = (long long)B * H * W, Mp = (M + 255) / 256 * 256;
+    const int ntaps = k * k, h = hidden;
+    auto need = [&](int Cout, int C) -> long long {
+        return (long long)dvd_conv_pick_nsplit(dtype, M, Cout, C, ntaps) * Mp * ((Cout + 255) / 256 * 256);
+    };
+    long long n = need(2 * h, h);
+    if (need(h, h) > n) n = need(h, h);
+    if (need(h, 2 * h) > n) n = need(h, 2 * h);
+    return n;
+}
+
 extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
     if (!d || !d->gx || !d->w_ur || !d->w_o || !d->h_all || !d->u_all || !d->hr_all || !d->ws) return DVD_E_ARG;
     if (!d->infer && (!d->r_all || !d->o_all)) return DVD_E_ARG;
@@ -271,6 +298,7 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
     const size_t astep = d->infer ? 0 : step;       // inference: u / h*r are one-step scratch, r and o are not stored at all
     const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, 2 * h, h, ntaps);
     const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);
+    const int nmax = !d->tickets ? 1 : d->combine_max > 0 ? d->combine_max : inlaunch_max();    // convs with up to nmax slices apply the gates in their epilogue
     const unsigned grid = cdiv(M * (h / 8), 256);
     for (int t = 0; t < d->T; ++t) {
         const char* hprev = t > 0 ? (const char*)d->h_all + (t - 1) * step : (const char*)d->h0;
@@ -284,9 +312,10 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
         GruEpi g = {};
         g.h = h; g.ldg = 3 * h; g.gx = gx; g.hprev = hprev; g.h32p = h32p; g.u_in = u;
         g.u = u; g.r = r; g.hr = hr; g.o = o; g.hn = hn; g.h32n = h32n;
-        if (hprev && ns_ur == 1) {           // enough output tiles: gates applied in the conv epilogue
+        g.slabs = d->ws; g.tickets = d->tickets;
+        if (hprev && ns_ur <= nmax) {                 // gates applied in the conv epilogue (split-K: by the tile's last workgroup)
             g.mode = 1;
-            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hprev, h, d->w_ur, d->w_ur_q, 2 * h, g, stream);
+            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hprev, h, d->w_ur, d->w_ur_q, 2 * h, g, ns_ur, stream);
             if (rc) return rc;
         } else {
             if (hprev) {
@@ -298,9 +327,9 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
                                                                             (const T*)hprev, (T*)u, (T*)r, (T*)hr, M, h));
         }
         ns = 0;
-        if (hprev && ns_o == 1) {
+        if (hprev && ns_o <= nmax) {
             g.mode = 2;
-            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hr, h, d->w_o, d->w_o_q, h, g, stream);
+            rc = conv_fused(d->dtype, d->B, d->H, d->W, d->k, hr, h, d->w_o, d->w_o_q, h, g, ns_o, stream);
             if (rc) return rc;
         } else {
             if (hprev) {
@@ -327,6 +356,7 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
     const size_t step = (size_t)M * h * esz;
     const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);        // d(hr)  = convT(d pre_o)
     const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, h, 2 * h, ntaps);   // dh    += convT(d pre_u | d pre_r)
+    const int nmax = !d->tickets ? 1 : d->combine_max > 0 ? d->combine_max : inlaunch_max();
     const unsigned grid = cdiv(M * (h / 8), 256);
     hipError_t e = hipMemsetAsync(d->carry, 0, (size_t)M * h * sizeof(float), S_);
     if (e != hipSuccess) return DVD_E_LAUNCH;
@@ -347,9 +377,11 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
         int ns = 0, rc;
         GruEpi g = {};
         g.h = h; g.ldg = 3 * h; g.r = const_cast<char*>(r); g.hprev = hprev; g.h32n = d->carry; g.o = dg;
-        if (hprev && ns_o == 1) {            // d(h*r) conv applies the reset-gate step in its epilogue
+        g.slabs = d->ws; g.tickets = d->tickets;
+        if (hprev && ns_o <= nmax) {                  // d(h*r) conv applies the reset-gate step in its epilogue
             g.mode = 3;
-            rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, d->wd_o_q, h, g, stream);
+            rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg + (size_t)2 * h * esz, h, 3 * h, d->wd_o, d->wd_o_q, h, g, ns_o,
+                                stream);
             if (rc) return rc;
         } else {
             if (hprev) {
@@ -362,7 +394,7 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
                                                                          (T*)dg, 3 * h, M, h));
         }
         if (hprev) {
-            if (ns_ur == 1) {                // [u|r] backward-data conv adds straight into the carry and goes on with
+            if (ns_ur <= nmax) {             // [u|r] backward-data conv adds straight into the carry and goes on with
                 g.mode = 4;                  // the first half of step t-1 (mode 5) unless this is step 0 with an h0
                 if (t > 0) {
                     const size_t tp = (size_t)(t - 1);
@@ -374,7 +406,7 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
                     g.o = (char*)d->dg + tp * M * 3 * h * esz;
                     out_done = true;
                 }
-                rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, d->wd_ur_q, h, g, stream);
+                rc = conv_fused_bwd(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, d->wd_ur_q, h, g, ns_ur, stream);
                 if (rc) return rc;
             } else {
                 rc = conv_slabs(d->dtype, d->B, d->H, d->W, d->k, dg, 2 * h, 3 * h, d->wd_ur, d->wd_ur_q, h, ns_ur, d->ws, stream);

@@ -120,7 +120,7 @@ extern "C" int dvd_clip_to_tensor(const unsigned char* src, const unsigned char*
     return launch_status();
 }
 
-extern "C" int dvd_abi_version(void) { return 9; }
+extern "C" int dvd_abi_version(void) { return 10; }
 extern "C" const char* dvd_strerror(int code) {
     switch (code) {
         case DVD_OK: return "ok";

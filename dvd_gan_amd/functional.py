@@ -346,6 +346,9 @@ class CondBatchNorm(Function):
 
 
 # ------------------------------------------------------------------ ConvGRU layer
+GRU_COMBINE_MAX = 0          # dvd_gru_desc.combine_max: 0 = the library's default policy (tests raise it to cover every slice count)
+
+
 class ConvGRULayer(Function):
     """All T steps of one ConvGRUCell (ConvGRU.py:29-54).  x: [T*B,S,S,Cin_p] t-major frames, or
     [B,S,S,Cin_p] when the same input feeds every step (first GRU of the generator).
@@ -382,7 +385,8 @@ class ConvGRULayer(Function):
         ns1 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), 2 * hid, hid, ntaps)
         ns2 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, hid, ntaps)
         ns3 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, 2 * hid, ntaps)
-        ws = torch.empty(max(ns1 * 2, ns2, ns3) * M * hid, dtype=torch.float32, device=dev)
+        ws_n = lib.dvd_convgru_ws_floats(L.dt(x), B, S1, S2, hid, k)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         d = L.GruDesc()
         d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.dt(x), T, B, S1, S2, hid, k
         d.gx_stride = 0 if shared_x else M * 3 * hid
@@ -398,6 +402,8 @@ class ConvGRULayer(Function):
         d.o_all = o_all.data_ptr() if o_all is not None else None
         d.h32 = h32.data_ptr() if h32 is not None else None
         d.ws = ws.data_ptr()
+        d.tickets = L.gru_tickets(dev).data_ptr()
+        d.combine_max = GRU_COMBINE_MAX
         d.infer = int(infer)
         L.check(lib.dvd_convgru_layer_forward(C.byref(d), L.stream()))
         if infer:
@@ -405,7 +411,7 @@ class ConvGRULayer(Function):
         ctx.save_for_backward(x, wu, wr, wo, h_all, u_all, r_all, o_all, hr_all, h0)
         ctx.params = (wu, bu, wr, br, wo, bo)
         ctx.packs = (px, pur, po)
-        ctx.meta = (T, B, S1, S2, hid, cin, k, shared_x, ws.numel())
+        ctx.meta = (T, B, S1, S2, hid, cin, k, shared_x, ws_n)
         return h_all.view(T * B, S1, S2, hid)
 
     @staticmethod
@@ -433,6 +439,8 @@ class ConvGRULayer(Function):
         d.h_all, d.u_all, d.r_all = h_all.data_ptr(), u_all.data_ptr(), r_all.data_ptr()
         d.o_all, d.hr_all = o_all.data_ptr(), hr_all.data_ptr()
         d.ws, d.dh_out, d.dg, d.carry = ws.data_ptr(), dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
+        d.tickets = L.gru_tickets(dev).data_ptr()
+        d.combine_max = GRU_COMBINE_MAX
         dh0_32 = None
         if h0 is not None and ctx.needs_input_grad[9]:          # gradient wrt the supplied initial state (ConvGRU.py:104)
             dh0_32 = torch.empty(M, hid, dtype=torch.float32, device=dev)

@@ -44,12 +44,13 @@ def lib():
         _lib.dvd_conv_wgrad_ws_floats.restype = C.c_longlong
         _lib.dvd_sepattn_work_floats.restype = C.c_longlong
         _lib.dvd_conv_fragment_major_bytes.restype = C.c_longlong
+        _lib.dvd_convgru_ws_floats.restype = C.c_longlong
         if _lib.dvd_abi_version() != ABI_VERSION:
             raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
     return _lib
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 BN_NREP = 16            # DVD_BN_NREP of include/dvdgan_hip.h
 
 
@@ -77,6 +78,19 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_tickets = {}
+
+
+def gru_tickets(device):
+    """The zero-initialised counters of dvd_gru_desc.tickets for the current stream of `device` (every launch leaves them at
+    zero, so one buffer per stream serves every ConvGRU layer issued on it)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(GRU_TICKETS, dtype=torch.int32, device=device)
+    return t
+
+
 class GruDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("hidden", C.c_int), ("k", C.c_int), ("gx_stride", C.c_longlong),
@@ -86,7 +100,11 @@ class GruDesc(C.Structure):
                 ("hr_all", C.c_void_p), ("h32", C.c_void_p), ("ws", C.c_void_p),
                 ("dh_out", C.c_void_p), ("dg", C.c_void_p), ("carry", C.c_void_p), ("dh0", C.c_void_p),
                 ("infer", C.c_int),
-                ("w_ur_q", C.c_void_p), ("w_o_q", C.c_void_p), ("wd_ur_q", C.c_void_p), ("wd_o_q", C.c_void_p)]
+                ("w_ur_q", C.c_void_p), ("w_o_q", C.c_void_p), ("wd_ur_q", C.c_void_p), ("wd_o_q", C.c_void_p),
+                ("tickets", C.c_void_p), ("combine_max", C.c_int)]
+
+
+GRU_TICKETS = 8192                      # == DVD_GRU_TICKETS
 
 
 class SnItem(C.Structure):              # == dvd_sn_item

@@ -183,9 +183,20 @@ typedef struct {
     /* optional: the four packs once more in fragment-major order (dvd_conv_fragment_major), or NULL -- handed to the recurrent
        convolutions as dvd_conv_desc.wq */
     const void* w_ur_q; const void* w_o_q; const void* wd_ur_q; const void* wd_o_q;
+    /* optional (ABI 10): DVD_GRU_TICKETS zero-initialised counters.  When given, a split-K recurrent convolution sums its slices
+       and applies the gate math INSIDE the launch (the last workgroup of an output tile to finish does it; nobody waits) instead
+       of leaving fp32 slabs to a separate gate kernel: two launches per step and pass instead of four.  Every launch leaves the
+       counters at zero; one buffer serves all layers issued on one stream, launches on different streams need their own.
+       NULL = slabs + gate kernels (ABI 9 behaviour). */
+    unsigned* tickets;
+    int combine_max;           /* largest split-K factor combined in-launch; 0 = the library's measured default (4: beyond that the
+                                  gate kernel, which spreads the slab reads over the whole chip, is faster)                       */
 } dvd_gru_desc;
+#define DVD_GRU_TICKETS 8192
 int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream);
 int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream);
+/* floats the caller provides as dvd_gru_desc.ws for a layer of this shape (slabs of whole output tiles) */
+long long dvd_convgru_ws_floats(int dtype, int B, int H, int W, int hidden, int k);
 int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps);
 
 /* ------------------------------------------------------------------------------------------

@@ -358,6 +358,71 @@ def test_convgru_small_frames_pixel_major_rows(shape):
         assert rel(prm.grad, sd[name].grad) < 2e-5, name
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 64, 4, 8, 256, 3), (2, 16, 16, 8, 128, 5), (3, 6, 8, 8, 64, 5), (2, 64, 8, 16, 128, 3)])
+def test_convgru_split_k_combined_inside_the_launch(shape, dtype, monkeypatch):
+    """Split-K recurrent convs whose slices are summed, and the gate math applied, by the tile's last workgroup to arrive
+    (conv_igemm.hip splitk_combine; dvd_gru_desc.tickets): several tiles x several slices, ragged last tile, both storage types.
+    Against the CPU oracle (exact mode), against the slab + gate-kernel route (tickets = NULL), bit-stable over repeats, counters
+    left at zero."""
+    import ctypes as C
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd import lib as L
+    from dvd_gan_amd.gen_net import ConvGRUCell
+    T, B, S, cin, hid, k = shape
+    ns = [L.lib().dvd_conv_pick_nsplit(L.dt(torch.empty(0, dtype=dtype)), C.c_longlong(B * S * S), co, ci, k * k)
+          for co, ci in ((2 * hid, hid), (hid, hid), (hid, 2 * hid))]
+    assert max(ns) > 1, ns
+    from dvd_gan_amd import functional as Fn
+    monkeypatch.setattr(Fn, "GRU_COMBINE_MAX", 8)      # (the default policy combines up to 2 slices in-launch; cover 4 and 8 as well)
+    torch.manual_seed(23)
+    cell = ConvGRUCell(cin, hid, k)
+    for p in cell.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.1)
+    sd = O.make_state({kk: v.detach().clone() for kk, v in cell.state_dict().items()}, requires_grad=True)
+    xs = torch.randn(T, B, cin, S, S)
+    gy = torch.randn(T, B, hid, S, S)
+    cell = cell.to(DEV)
+
+    def run():
+        for p in cell.parameters():
+            p.grad = None
+        xg = xs.reshape(T * B, cin, S, S).to(DEV).requires_grad_(True)
+        got = ncl(cell.run(cl(xg, dtype), T, False), hid).view(T, B, hid, S, S)
+        (got * gy.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return [got.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in cell.parameters()]
+
+    new = run()
+    assert int(L.gru_tickets(torch.device(DEV, torch.cuda.current_device())).abs().sum()) == 0
+    for _ in range(5):
+        for a, b in zip(new[:2], run()[:2]):      # (h of every step; dx = a deterministic conv of the BPTT's gate gradients)
+            assert torch.equal(a, b), "the in-launch combine must not depend on which slice arrives last"
+
+    class _NoTickets:
+        @staticmethod
+        def data_ptr():
+            return None
+    monkeypatch.setattr(L, "gru_tickets", lambda dev: _NoTickets)
+    old = run()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(new, old):
+        assert rel(a, b.cpu()) < tol
+    if dtype == torch.float32:
+        xr = xs.clone().requires_grad_(True)
+        h, want = None, []
+        for i in range(T):
+            h = O.convgru_cell(sd, "", xr[i], h)
+            want.append(h)
+        want = torch.stack(want)
+        (want * gy).sum().backward()
+        assert rel(new[0], want.detach()) < 1e-5
+        assert rel(new[1].view(T, B, cin, S, S), xr.grad) < 2e-5
+        for (name, _), g in zip(cell.named_parameters(), new[2:]):
+            assert rel(g, sd[name].grad) < 2e-5, name
+
+
 # ------------------------------------------------------------------ BASELINE configs[3] frame size (128 x 128)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_discriminators_at_128x128_frames(dtype):

@@ -45,7 +45,9 @@ def setup(name, S, cin, hid, k, B, T, dev, dt, lib):
     h32 = torch.empty(2, M, hid, dtype=torch.float32, device=dev)
     ntaps = k * k
     ns = [lib.dvd_conv_pick_nsplit(L.BF16, C.c_longlong(M), co, ci, ntaps) for co, ci in ((2 * hid, hid), (hid, hid), (hid, 2 * hid))]
-    ws = torch.empty(max(ns[0] * 2, ns[1], ns[2]) * M * hid, dtype=torch.float32, device=dev)
+    lib.dvd_convgru_ws_floats.restype = C.c_longlong
+    ws = torch.empty(lib.dvd_convgru_ws_floats(L.BF16, B, S, S, hid, k), dtype=torch.float32, device=dev)
+    tickets = torch.zeros(L.GRU_TICKETS, dtype=torch.int32, device=dev)    # per layer: `pairs` / `halves` run layers on two streams
     d = L.GruDesc()
     d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.BF16, T, B, S, S, hid, k
     d.gx_stride = M * 3 * hid
@@ -56,11 +58,13 @@ def setup(name, S, cin, hid, k, B, T, dev, dt, lib):
         d.wd_ur_q, d.wd_o_q = pur.fragment_major("wd").data_ptr(), po.fragment_major("wd").data_ptr()
     d.h_all, d.u_all, d.r_all, d.o_all, d.hr_all = (t.data_ptr() for t in bufs)
     d.h32, d.ws = h32.data_ptr(), ws.data_ptr()
+    if os.environ.get("DVD_GRU_TICKETS", "1") != "0":
+        d.tickets = tickets.data_ptr()
     dh = (torch.randn(T, M, hid, device=dev) * 0.1).to(dt)
     dg = torch.empty(T, M, 3 * hid, dtype=dt, device=dev)
     carry = torch.empty(M, hid, dtype=torch.float32, device=dev)
     d.dh_out, d.dg, d.carry = dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
-    keep += bufs + [h32, ws, dh, dg, carry]
+    keep += bufs + [h32, ws, dh, dg, carry, tickets]
     return d, keep
 
 
