@@ -1040,7 +1040,9 @@ __device__ __forceinline__ void conv_halo_tile(const ConvK& p, char* const smem,
 }
 
 template <typename T, int TM, int WN, bool RELU, bool UP2, int WMV = 2>
-__global__ __launch_bounds__(64 * WMV * WN) void conv_halo_kernel(ConvK p) {
+// (bf16: two workgroups per CU, i.e. at most 256 registers incl. the accumulators -- without the bound hipcc moves all 128 accumulators
+//  into arch VGPRs for the in-launch split-K combine: 348 registers, one workgroup per CU)
+__global__ __launch_bounds__(64 * WMV * WN, sizeof(T) == 2 ? 2 : 1) void conv_halo_kernel(ConvK p) {
     __shared__ __attribute__((aligned(16))) char smem[HaloCfg<T, TM, WN, UP2, WMV>::LDSB];
     int bid = blockIdx.x;
     {
