@@ -489,8 +489,14 @@ class ConvGRULayer(Function):
 
 
 # ------------------------------------------------------------------ attention / head / loss
+ATTN_MFMA = _os.environ.get("DVD_ATTN_MFMA", "1") != "0"      # A/B aid: 0 = the fp32 vector-pipe attention kernels also in bf16 mode
+
+
 class SelfAttention2d(Function):
-    """y = gamma * softmax(q^T k) v + x      Discriminators.py:100-119; qkv from one fused 1x1 conv."""
+    """y = gamma * softmax(q^T k) v + x      Discriminators.py:100-119; qkv from one fused 1x1 conv.
+    bf16 storage at the discriminators' widths (16 query channels, 32 / 64 / 128 value channels, <= 256 tokens per frame) runs
+    on the matrix cores and keeps one number per query (dvd_attention_mfma_*); everything else runs the fp32 kernels, which keep
+    the N x N map for the backward pass."""
 
     @staticmethod
     def forward(ctx, x, qkv, gamma, dq, C_real):
@@ -499,14 +505,23 @@ class SelfAttention2d(Function):
         koff = K.pad8(dq)
         voff = 2 * koff
         ctx.gamma_param = gamma
+        lib = L.lib()
+        ctx.mfma = bool(ATTN_MFMA and lib.dvd_attention_mfma_ok(L.dt(x), qkv.shape[-1], dq, koff, voff, x.shape[-1], C_real, N))
+        ctx.meta = (dq, C_real, koff, voff, N)
+        if ctx.mfma:
+            y, att = torch.empty_like(x), torch.empty_like(x)
+            lse = torch.empty(F_, N, dtype=torch.float32, device=x.device)
+            L.check(lib.dvd_attention_mfma_forward(L.ptr(qkv), qkv.shape[-1], L.ptr(x), C_real, L.ptr(gamma), L.ptr(y),
+                                                   L.ptr(att), L.ptr(lse), C.c_longlong(F_), N, L.stream()))
+            ctx.save_for_backward(qkv, gamma, att, lse)
+            return y
         y = torch.zeros_like(x) if x.shape[-1] != C_real else torch.empty_like(x)
         att = torch.zeros_like(x)
         A = torch.empty(F_, N, N, dtype=torch.float32, device=x.device)
-        L.check(L.lib().dvd_attention_forward(L.dt(x), L.ptr(qkv), qkv.shape[-1], dq, koff, voff, L.ptr(x), x.shape[-1],
-                                              C_real, L.ptr(gamma), L.ptr(y), L.ptr(att), L.ptr(A), C.c_longlong(F_), N,
-                                              L.stream()))
+        L.check(lib.dvd_attention_forward(L.dt(x), L.ptr(qkv), qkv.shape[-1], dq, koff, voff, L.ptr(x), x.shape[-1],
+                                          C_real, L.ptr(gamma), L.ptr(y), L.ptr(att), L.ptr(A), C.c_longlong(F_), N,
+                                          L.stream()))
         ctx.save_for_backward(qkv, gamma, att, A)
-        ctx.meta = (dq, C_real, koff, voff, N)
         return y
 
     @staticmethod
@@ -515,10 +530,17 @@ class SelfAttention2d(Function):
         dq, C_real, koff, voff, N = ctx.meta
         dy = dy.contiguous()
         F_ = dy.shape[0]
-        dqkv = torch.zeros_like(qkv)
-        dS = torch.empty_like(A)
         direct = ctx.needs_input_grad[2] and _direct(ctx.gamma_param)       # the kernel ADDS into dgamma: persistent .grad taken as is
         dgamma = ctx.gamma_param.grad if direct else torch.zeros(1, dtype=torch.float32, device=dy.device)
+        if ctx.mfma:                                                         # (A is the [F, N] log-sum-exp here)
+            dqkv = torch.empty_like(qkv) if qkv.shape[-1] == 32 + C_real else torch.zeros_like(qkv)
+            D = torch.empty_like(A)
+            L.check(L.lib().dvd_attention_mfma_backward(L.ptr(qkv), qkv.shape[-1], L.ptr(dy), C_real, L.ptr(gamma), L.ptr(att),
+                                                        L.ptr(A), L.ptr(D), L.ptr(dqkv), L.ptr(dgamma), C.c_longlong(F_), N,
+                                                        L.stream()))
+            return dy, dqkv, (None if direct else dgamma), None, None
+        dqkv = torch.zeros_like(qkv)
+        dS = torch.empty_like(A)
         L.check(L.lib().dvd_attention_backward(L.dt(dy), L.ptr(qkv), qkv.shape[-1], dq, koff, voff, L.ptr(dy),
                                                dy.shape[-1], C_real, L.ptr(gamma), L.ptr(att), L.ptr(A), L.ptr(dS),
                                                L.ptr(dqkv), L.ptr(dgamma), C.c_longlong(F_), N, L.stream()))

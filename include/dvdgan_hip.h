@@ -303,6 +303,16 @@ int dvd_attention_forward(int dtype, const void* qkv, int ldq, int dq, int koff,
 int dvd_attention_backward(int dtype, const void* qkv, int ldq, int dq, int koff, int voff, const void* dy, int ldx,
                            int C, const float* gamma, const void* att_out, const float* A, float* dS, void* dqkv,
                            float* dgamma, long long frames, int N, void* stream);
+/* The same block on the matrix cores (bf16 storage, ABI 10): nothing N x N is kept -- the forward leaves `lse` [frames][N]
+ * (log-sum-exp of each query's score row), the backward recomputes the probabilities from q, k and lse; D is scratch
+ * [frames][N].  q | k | v at columns 0 | 16 | 32 of qkv (16 query / key channels), C = 32 / 64 / 128 = ldx, N = 32 .. 256 in
+ * whole 32-token blocks: dvd_attention_mfma_ok says whether a call qualifies (everything else: the fp32 kernels above). */
+int dvd_attention_mfma_ok(int dtype, int ldq, int dq, int koff, int voff, int ldx, int C, int N);
+int dvd_attention_mfma_forward(const void* qkv, int ldq, const void* x, int C, const float* gamma, void* y, void* att_out,
+                               float* lse, long long frames, int N, void* stream);
+int dvd_attention_mfma_backward(const void* qkv, int ldq, const void* dy, int C, const float* gamma, const void* att_out,
+                                const float* lse, float* D, void* dqkv /* every q | k | v column is written */,
+                                float* dgamma /* += */, long long frames, int N, void* stream);
 
 /* Spatio-temporal self attention (Module/Attention.py:114-185, SelfAttention over the T*H*W token axis; defined by the
  * reference, not invoked by its Generator): queries from `q` (N rows per clip), keys / values from `kv` -- the

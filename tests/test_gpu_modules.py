@@ -151,6 +151,57 @@ def test_attention(golden, tag, C, dtype):
     check_param_grads(at, sub(g, "grad"), gt)
 
 
+@pytest.mark.parametrize("C,S,F", [(128, 16, 5), (128, 8, 7), (64, 16, 3)])
+def test_attention_on_the_matrix_cores(C, S, F, monkeypatch):
+    """bf16 mode at the discriminators' widths (Discriminators.py:100-119 at 4 * chn = 128 channels, 16 x 16 and 8 x 8 maps):
+    the MFMA kernels (attn_mfma.hip: no N x N map kept, probabilities recomputed in the backward pass) against the CPU oracle on
+    bf16-rounded inputs and against the fp32 vector-pipe kernels of attn.hip in the same mode."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd import functional as Fn
+    from dvd_gan_amd import lib as L
+    from dvd_gan_amd.disc_nets import SelfAttention
+    assert L.lib().dvd_attention_mfma_ok(L.BF16, 32 + C, 16 if C == 128 else C // 8, 16, 32, C, C, S * S) == (1 if C == 128 else 0)
+    torch.manual_seed(31)
+    at = SelfAttention(C)
+    at.gamma.data.fill_(0.7)
+    for p in (at.query_conv, at.key_conv, at.value_conv):
+        p.bias.data.normal_(0, 0.1)
+    at.query_conv.weight.data.mul_(2.0)        # scores of a few units: a softmax that is neither flat nor one-hot
+    bf = lambda v: v.to(torch.bfloat16).float()
+    for p in at.parameters():
+        p.data = bf(p.data)
+    sd = O.make_state({k: v.detach().clone() for k, v in at.state_dict().items()}, requires_grad=True)
+    x0 = bf(torch.randn(F, C, S, S))
+    gy = bf(torch.randn(F, C, S, S))
+    xr = x0.clone().requires_grad_(True)
+    want = O.self_attention_2d(sd, "", xr)
+    (want * gy).sum().backward()
+    at = at.to(DEV)
+
+    def run():
+        for p in at.parameters():
+            p.grad = None
+        xg = x0.to(DEV).requires_grad_(True)
+        y = ncl(at(cl(xg, torch.bfloat16)), C)
+        (y * gy.to(DEV)).sum().backward()
+        return [y.detach(), xg.grad] + [p.grad.clone() for p in at.parameters()]
+
+    got = run()
+    monkeypatch.setattr(Fn, "ATTN_MFMA", False)
+    ref = run()
+    names = ["y", "dx"] + [n for n, _ in at.named_parameters()]
+    wants = [want.detach(), xr.grad] + [sd[n].grad for n, _ in at.named_parameters()]
+    scale = max(float(w.abs().max()) for w in wants[2:])
+    for n, a, b, w in zip(names, got, ref, wants):
+        # the vector-pipe kernels see the same bf16 q | k | v; the oracle is fp32 throughout
+        if float(w.abs().max()) < 1e-4 * scale:
+            # zero in exact arithmetic (the key bias shifts every score of a row alike): rounding noise only, in the reference too
+            assert float(a.abs().max()) < 3e-2 * scale, (n, float(a.abs().max()), scale)
+            continue
+        assert rel(a, w) < (3e-2 if C == 128 else 1e-1), (n, rel(a, w), rel(b.cpu(), w))      # (C = 64: 8 query channels, the fp32 kernels both times)
+        assert rel(a, w) < 2.5 * rel(b.cpu(), w) + 2e-3, (n, rel(a, w), rel(b.cpu(), w))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_3d_golden(golden, dtype):
     """Module/Attention.py:114-185 (T*W*H tokens, 2x2x2 max-pooled keys / values) against the reference fixture."""
