@@ -349,45 +349,13 @@ class CondBatchNorm(Function):
 GRU_COMBINE_MAX = 0          # dvd_gru_desc.combine_max: 0 = the library's default policy (tests raise it to cover every slice count)
 
 
-def gru_packs(dtype, dev, wu, wr, wo, alloc_only, frag=False):
-    """The three MFMA weight images of one ConvGRU layer: x-part [u|r|o], h-part [u|r] and [o] (ConvGRU.py:47-51 split by
-    linearity).  alloc_only: buffers only (current stream); fill_gru_packs launches the packing -- on whatever stream is current
-    then.  frag: also the fragment-major images of all six packs (bf16, power-of-two frames: every conv of the layer wants them)."""
-    hid, ctot, k = wu.shape[0], wu.shape[1], wu.shape[-1]
-    cin = ctot - hid
-    px = K.PackedConv(dtype, 3 * hid, cin, (k, k), dev, covered=True)     # the fills below write every output channel
-    pur = K.PackedConv(dtype, 2 * hid, hid, (k, k), dev, covered=True)
-    po = K.PackedConv(dtype, hid, hid, (k, k), dev, covered=True)
-    if frag:
-        for pk in (px, pur, po):
-            pk.fragment_major("wf", alloc_only=True)
-            pk.fragment_major("wd", alloc_only=True)
-    if not alloc_only:
-        fill_gru_packs((px, pur, po), wu, wr, wo, frag)
-    return px, pur, po
-
-
-def fill_gru_packs(packs, wu, wr, wo, frag=False):
-    px, pur, po = packs
-    hid = wu.shape[0]
-    cin = wu.shape[1] - hid
-    for g, w in enumerate((wu, wr, wo)):
-        px.fill(w, co_off=g * hid, ci_off=0)
-    pur.fill(wu, co_off=0, ci_off=cin).fill(wr, co_off=hid, ci_off=cin)
-    po.fill(wo, ci_off=cin)
-    if frag:
-        for pk in packs:
-            pk.fragment_major("wf")
-            pk.fragment_major("wd")
-
-
 class ConvGRULayer(Function):
     """All T steps of one ConvGRUCell (ConvGRU.py:29-54).  x: [T*B,S,S,Cin_p] t-major frames, or
     [B,S,S,Cin_p] when the same input feeds every step (first GRU of the generator).
     Returns h for every step as [T*B,S,S,hidden]."""
 
     @staticmethod
-    def forward(ctx, x, wu, bu, wr, br, wo, bo, T, shared_x, h0, infer=False, packs=None):
+    def forward(ctx, x, wu, bu, wr, br, wo, bo, T, shared_x, h0, infer=False):
         """infer (the caller runs under torch.no_grad(): the sampling path, trainer.py:323-334): nothing is kept for a
         backward pass -- u and h*r live in one-step scratch buffers, r and o are not stored at all (4 of the 5 [T, ...] tensors
         of the training forward are never allocated, a seventh of the gate epilogues' traffic is not written)."""
@@ -397,11 +365,13 @@ class ConvGRULayer(Function):
         B = x.shape[0] if shared_x else x.shape[0] // T
         S1, S2 = x.shape[1], x.shape[2]
         M = B * S1 * S2
-        if packs is not None:              # prepared on the side stream by prefetch_gru_packs
-            px, pur, po, ev = packs
-            torch.cuda.current_stream(dev).wait_event(ev)
-        else:
-            px, pur, po = gru_packs(dtype, dev, wu, wr, wo, alloc_only=False)
+        px = K.PackedConv(dtype, 3 * hid, cin, (k, k), dev, covered=True)     # the fills below write every output channel
+        pur = K.PackedConv(dtype, 2 * hid, hid, (k, k), dev, covered=True)
+        po = K.PackedConv(dtype, hid, hid, (k, k), dev, covered=True)
+        for g, w in enumerate((wu, wr, wo)):
+            px.fill(w, co_off=g * hid, ci_off=0)
+        pur.fill(wu, co_off=0, ci_off=cin).fill(wr, co_off=hid, ci_off=cin)
+        po.fill(wo, ci_off=cin)
         bias3 = torch.cat([bu, br, bo])
         gx = K.conv_forward(x, px.wf, (k, k), 3 * hid, bias=bias3, wq=lambda: px.fragment_major("wf"))
         mk = lambda n=T: torch.empty(n, B, S1, S2, hid, dtype=dtype, device=dev)
@@ -515,7 +485,7 @@ class ConvGRULayer(Function):
         dh0 = None
         if dh0_32 is not None:
             dh0 = dh0_32.view(h0.shape) if h0.dtype == torch.float32 else K.convert(dh0_32, h0.dtype).view(h0.shape)
-        return (dx, grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2], None, None, dh0, None, None)
+        return (dx, grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2], None, None, dh0, None)
 
 
 # ------------------------------------------------------------------ attention / head / loss

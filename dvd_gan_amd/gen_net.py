@@ -34,10 +34,9 @@ class ConvGRUCell(nn.Module):
         self.out_gate = ConvParams(input_size + hidden_size, hidden_size, k, "orthogonal")
 
     def run(self, x, T, shared_x, h0=None):
-        packs, self._packs = getattr(self, "_packs", None), None      # (prepared by Generator.forward on the side stream, used once)
         return Fn.ConvGRULayer.apply(x, self.update_gate.weight, self.update_gate.bias, self.reset_gate.weight,
                                      self.reset_gate.bias, self.out_gate.weight, self.out_gate.bias, T, shared_x, h0,
-                                     not torch.is_grad_enabled(), packs)
+                                     not torch.is_grad_enabled())
 
 
 class ConvGRU(nn.Module):
@@ -153,42 +152,10 @@ class Generator(nn.Module):
         [B, hidden_l, S, S] fp32 (None entries = zeros).  They take the place of the `hidden=None` the reference passes at
         the first frame (Generator.py:91,96 -> ConvGRU.forward(x, hidden), ConvGRU.py:104-118) and receive gradients."""
         sn = prefetch_spectral_norm(self, self.compute_dtype)    # SN + weight packing of all layers on the side stream
-        cells = self._prefetch_gru_packs(x.device)
         try:
             return self._forward(x, class_id, hidden)
         finally:
             clear_spectral_norm(sn)
-            for c in cells:
-                c._packs = None
-
-    def _prefetch_gru_packs(self, dev):
-        """The MFMA weight images of the twelve ConvGRU layers (three packs each, plus their fragment-major copies in bf16 mode)
-        are built on the spectral-norm side stream at the start of the forward pass instead of in front of each layer's first
-        convolution on the step's dependent chain (~90 packing + ~70 re-ordering launches per generator forward); a layer waits
-        for its own event.  Buffers are allocated in main-stream order."""
-        cells = [c for m in self.conv if isinstance(m, ConvGRU) for c in m.cells]
-        if not cells or dev.type != "cuda" or _os.environ.get("DVD_GRU_PREFETCH", "1") == "0":
-            return []
-        from .sn_layers import side_stream_for
-        main, side = torch.cuda.current_stream(dev), side_stream_for(dev)
-        S, frag_ok, prepared = self.latent_dim, [], []
-        for m in self.conv:
-            if isinstance(m, ConvGRU):
-                pow2 = S >= 4 and (S & (S - 1)) == 0
-                frag_ok += [self.compute_dtype == torch.bfloat16 and pow2 and c.kernel_size in (3, 5) for c in m.cells]
-            elif getattr(m, "upsample_factor", 1) != 1:
-                S *= 2
-        for c, fr in zip(cells, frag_ok):
-            w = (c.update_gate.weight, c.reset_gate.weight, c.out_gate.weight)
-            prepared.append((Fn.gru_packs(self.compute_dtype, dev, *w, alloc_only=True, frag=fr), w, fr))
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for c, (packs, w, fr) in zip(cells, prepared):
-                Fn.fill_gru_packs(packs, *[t.data for t in w], frag=fr)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                c._packs = (*packs, ev)
-        return cells
 
     def _count_batches(self, dev):
         """BatchNorm2d's `num_batches_tracked += 1` of all sixteen conditional batch norms (Normalization.py:72, train mode) as ONE

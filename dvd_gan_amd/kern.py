@@ -73,22 +73,17 @@ class PackedConv:
         self.wf = af(self.ntaps, cout_tot, self.cip, dtype=dtype, device=device)
         self.wd = ad(self.ntaps, self.cip, self.cop, dtype=dtype, device=device) if need_dgrad else None
 
-    def fragment_major(self, which="wf", alloc_only=False):
+    def fragment_major(self, which="wf"):
         """The forward ("wf") or backward-data ("wd") image once more in fragment-major order (dvd_conv_fragment_major), for
-        the convolution kernel that reads its weight operand straight from L2; built on first use, after the last fill().
-        alloc_only: reserve the buffer now (on the current stream) and build it at the next call -- for a caller that fills it
-        on another stream."""
+        the convolution kernel that reads its weight operand straight from L2; built on first use, after the last fill()."""
         q = getattr(self, which + "q", None)
-        src = getattr(self, which)
-        cout, c = (self.cout, self.cip) if which == "wf" else (self.cip, self.cop)
         if q is None:
+            src = getattr(self, which)
+            cout, c = (self.cout, self.cip) if which == "wf" else (self.cip, self.cop)
             n = L.lib().dvd_conv_fragment_major_bytes(self.ntaps, cout, c)
             q = torch.empty(n // 2, dtype=src.dtype, device=src.device)
-            setattr(self, which + "q", q)
-            setattr(self, which + "q_ready", False)
-        if not alloc_only and not getattr(self, which + "q_ready"):
             L.check(L.lib().dvd_conv_fragment_major(L.dt(src), L.ptr(src), L.ptr(q), self.ntaps, cout, c, L.stream()))
-            setattr(self, which + "q_ready", True)
+            setattr(self, which + "q", q)
         return q
 
     def fill(self, w, sigma=None, co_off=0, ci_off=0):

@@ -109,14 +109,6 @@ class SpectralNormConv(nn.Module):
 _SN_STREAMS = {}
 
 
-def side_stream_for(dev):
-    """The per-device side stream the weight preparations (spectral norm, weight images) are issued on."""
-    side = _SN_STREAMS.get(dev.index)
-    if side is None:
-        side = _SN_STREAMS[dev.index] = torch.cuda.Stream(dev)
-    return side
-
-
 def prefetch_spectral_norm(net, dtype):
     """Spectral norm of every SN conv of `net` for the forward that is starting: power iteration + sigma + the
     sigma-normalised MFMA weight images, all issued on a side stream (the reference does this inside each layer's
@@ -128,7 +120,9 @@ def prefetch_spectral_norm(net, dtype):
         return mods
     dev = mods[0].module.weight_bar.device
     main = torch.cuda.current_stream(dev)
-    side = side_stream_for(dev)
+    side = _SN_STREAMS.get(dev.index)
+    if side is None:
+        side = _SN_STREAMS[dev.index] = torch.cuda.Stream(dev)
     bufs = [m._alloc(dtype, dev) for m in mods]          # allocated (and zero-filled) in main-stream order
     if os.environ.get("DVD_SN_BATCHED", "1") != "0":
         # ONE item table, four launches for the whole network (dvd_sn_batched: W^T u, W v, finish, packs) instead of five
@@ -147,23 +141,11 @@ def prefetch_spectral_norm(net, dtype):
         host = torch.empty(C.sizeof(items), dtype=torch.uint8, pin_memory=True)
         C.memmove(host.data_ptr(), C.addressof(items), C.sizeof(items))
         scratch = torch.empty(max(1, nfl.value), dtype=torch.float32, device=dev)
-        # bf16 mode: the fragment-major copies of the 3 x 3 (x 3) images (the convolution kernels that read their weights straight
-        # from L2 want them) are made here too instead of in front of each conv on the main stream; buffers in main-stream order
-        fragq = []
-        if dtype == torch.bfloat16 and os.environ.get("DVD_SN_FRAG_SIDE", "1") != "0":
-            for _, pack in bufs:
-                if pack.k[1] == pack.k[2] and pack.k[1] in (3, 5):
-                    for which in ("wf", "wd"):
-                        if getattr(pack, which) is not None:
-                            pack.fragment_major(which, alloc_only=True)
-                            fragq.append((pack, which))
         side.wait_stream(main)
         with torch.cuda.stream(side):
             table = host.to(dev, non_blocking=True)
             L.check(L.lib().dvd_sn_batched(items, C.c_void_p(table.data_ptr()), n, C.c_void_p(scratch.data_ptr()),
                                            C.c_void_p(side.cuda_stream)))
-            for pack, which in fragq:
-                pack.fragment_major(which)
             ev = torch.cuda.Event()
             ev.record(side)
         scratch.record_stream(side)
