@@ -2388,6 +2388,7 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     const long long M = pl.M;
     const bool halo = pl.halo, thin = pl.thin, wide = pl.wide, big = pl.big;
     dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
+    if (g && p.nsplit > 1 && grid.x > DVD_GRU_TICKETS) return DVD_E_SHAPE;      // one ticket per output tile (the small-frame grid below is no larger)
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
                    d->kt * d->kh * d->kw, p.nsplit, d->up2 | (d->relu_in << 1) | ((d->ws != nullptr) << 2));
     hipStream_t st = (hipStream_t)stream;

@@ -305,7 +305,7 @@ int dvd_attention_backward(int dtype, const void* qkv, int ldq, int dq, int koff
                            float* dgamma, long long frames, int N, void* stream);
 /* The same block on the matrix cores (bf16 storage, ABI 10): nothing N x N is kept -- the forward leaves `lse` [frames][N]
  * (log-sum-exp of each query's score row), the backward recomputes the probabilities from q, k and lse; D is scratch
- * [frames][N].  q | k | v at columns 0 | 16 | 32 of qkv (16 query / key channels), C = 32 / 64 / 128 = ldx, N = 32 .. 256 in
+ * [frames][N].  q | k | v at columns 0 | 16 | 32 of qkv (16 query / key channels), C = 32 / 64 / 128 = ldx, N = 32 .. 4096 in
  * whole 32-token blocks: dvd_attention_mfma_ok says whether a call qualifies (everything else: the fp32 kernels above). */
 int dvd_attention_mfma_ok(int dtype, int ldq, int dq, int koff, int voff, int ldx, int C, int N);
 int dvd_attention_mfma_forward(const void* qkv, int ldq, const void* x, int C, const float* gamma, void* y, void* att_out,
