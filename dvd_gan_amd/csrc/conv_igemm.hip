@@ -2506,7 +2506,10 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
                         // (1536,8192) 267, (3072,4096) 247, (4096,4096) 243, (6144,4096) 242, (8192,2048) 252
         static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 2048;   // re-swept with whole-round grids: 4096 185.6, 2048 183.2, 1024 183.5 ms
         static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 4096;
-        static const long long tgt_row = getenv("DVD_WGR_TGT") ? atoll(getenv("DVD_WGR_TGT")) : 1536;   // swept with whole-round grids: 1024 187.7, 1536 185.1, 2048 190.8, 3072 192.2 ms
+        // (rounds 1-3, swept with whole-round grids: 1024 187.7, 1536 185.1, 2048 190.8, 3072 192.2 ms of weight gradients.  End of round 4 -- the
+        //  chain's kernels no longer leave the side stream the CUs they used to -- fewer, longer slices win on the STEP: 256 503.4 / 503.8,
+        //  384 498.1 / 498.1, 512 495.6 / 495.7, 768 497.7 / 498.5, 1024 498.4 / 497.3, 1536 500.4 / 500.3, 3072 501.3 ms, one box)
+        static const long long tgt_row = getenv("DVD_WGR_TGT") ? atoll(getenv("DVD_WGR_TGT")) : 512;
         const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps);
         msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
         const long long cap = M / minrows > 0 ? M / minrows : 1;
