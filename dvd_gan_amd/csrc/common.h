@@ -111,6 +111,9 @@ struct GruEpi {
     float* slabs; unsigned* tickets;
 };
 extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream);
+// Internal: weight gradients with 3 (8) channels on one side and 64 on the other (wgrad_thin.hip); 0 floats = not served there
+long long dvd_wgrad_thin_ws_floats(const dvd_wgrad_desc* d);
+int dvd_wgrad_thin(const dvd_wgrad_desc* d, void* stream);
 
 static inline int ilog2_exact(int v) {   // host: log2 of a power of two, -1 otherwise
     if (v <= 0 || (v & (v - 1))) return -1;

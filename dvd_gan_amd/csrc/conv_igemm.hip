@@ -2257,7 +2257,7 @@ extern "C" void dvd_prof_enable(int on) {
 // kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Drains the records of `kind` and returns the number of
 // launches; n / ms / flops (each [nvar] or NULL) receive the per-variant totals -- kind 0: 1 = conv_halo 256 x 128,
 // 2 = conv_halo 128 x 128, 3 = conv_halo 256 x 64 (thin outputs), 4 = conv_igemm 128 x 128, 5 = conv_igemm 256 x 128,
-// 6 = conv_igemm 256 x 256 (8 waves), 7 / 8 = whole-frame footprint kernel (4 x 4 / 8 x 8 frames) 256 x 128 / 128 x 128; kind 1: 1 = filter-row kernel, 2 = one-tap kernel; index 0 = everything.
+// 6 = conv_igemm 256 x 256 (8 waves), 7 / 8 = whole-frame footprint kernel (4 x 4 / 8 x 8 frames) 256 x 128 / 128 x 128; kind 1: 1 = filter-row kernel, 2 = one-tap kernel, 3 = thin-end kernel (wgrad_thin.hip); index 0 = everything.
 // If the environment variable DVD_PROF_CSV is set, every drained record is appended to that file.
 extern "C" long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops) {
     std::lock_guard<std::mutex> l(g_prof_mu);
@@ -2540,6 +2540,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
 
 extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
     WgK p; dim3 grid; int ta, tb, mode; long long msplit;
+    if (const long long thin = dvd_wgrad_thin_ws_floats(d)) return thin;       // 3 (8) channels on one side: wgrad_thin.hip
     if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
     if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) + msplit * (long long)grid.x * (ta * 64);   // + bias partials
     return msplit * (long long)grid.x * (ta * 64) * (tb * 64);
@@ -2550,6 +2551,12 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     const int rc = wgrad_plan(d, p, grid, ta, tb, msplit, mode);
     if (rc != DVD_OK) return rc;
     const int ntaps = d->kt * d->kh * d->kw;
+    if (d->ws && dvd_wgrad_thin_ws_floats(d)) {    // the thin ends of the networks (stems, RGB layer): taps folded into the matrix dimension
+        if (d->overwrite && (d->s_tap != 1 || d->s_ci != ntaps || d->s_co != (long long)d->Cin_real * ntaps)) return DVD_E_ARG;
+        ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, 0, d->relu_in << 1);
+        prof.r.variant = 3;
+        return dvd_wgrad_thin(d, stream);
+    }
     if (d->ws && msplit > 1) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw
     const int overwrite = d->overwrite != 0;       // dw = result instead of dw += result (the caller need not zero it)
     if (overwrite) {

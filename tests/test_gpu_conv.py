@@ -77,6 +77,12 @@ CASES = [
     # filter-row weight-gradient kernel on 4 x 4 frames (round 4): a 32-pixel step = two whole frames
     (6, 72, 200, (4, 4), (3, 3), False, True),
     (10, 136, 72, (4, 4), (5, 5), False, False),
+    # the thin ends of the networks in bf16 mode (wgrad_thin.hip: 3 channels on one side, 64 on the other, taps folded into the
+    # matrix dimension; exact mode takes the general kernels on the same cases)
+    (5, 3, 64, (32, 32), (3, 3), False, False),          # a discriminator stem: x thin, bias gradient through the 1.0 column
+    (2, 3, 64, (5, 16, 16), (3, 3, 3), False, True),     # 3-D stem, T = 5, ReLU on the thin input
+    (3, 64, 3, (64, 64), (3, 3), False, True),           # the RGB layer: dy thin (taps mirrored), ReLU on the wide input
+    (2, 64, 2, (3, 32, 32), (3, 3, 3), False, False),    # dy thin, 3-D
     # extents that are not powers of two (latent_dim 3 / 6: 6, 12, 24, 48, 96 pixels): division indexing, tap-by-tap kernels
     (3, 16, 24, (6, 6), (3, 3), False, False),
     (2, 24, 40, (12, 12), (5, 5), False, True),
