@@ -233,7 +233,7 @@ def main():
                       3: hk + "<%s, 256x64 tile>" % a.dtype, 4: "conv_igemm_kernel<%s, 128x128 tile>" % a.dtype,
                       5: "conv_igemm_kernel<%s, 256x128 tile>" % a.dtype, 6: "conv_igemm_kernel<bf16, 256x256 tile, 8 waves>",
                       7: "conv_halo_gbs_kernel<bf16, 256x128 tile, 8x8 frames>",
-                      8: "conv_halo_gbs_kernel<bf16, 128x128 tile, 4x4 / 8x8 frames>"},
+                      8: "conv_halo_gbs_kernel<bf16, 128x128 tile, 4x4 / 8x8 frames>", 9: "conv_thin_in_kernel<bf16, 3 -> 64 channels>"},
                   1: {1: "conv_wgrad_row_kernel", 2: "conv_wgrad_kernel", 3: "wgrad_thin_kernel"}}
         for kind, name in ((0, "conv_igemm"), (1, "conv_wgrad")):
             NV = 10

@@ -114,6 +114,9 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
 // Internal: weight gradients with 3 (8) channels on one side and 64 on the other (wgrad_thin.hip); 0 floats = not served there
 long long dvd_wgrad_thin_ws_floats(const dvd_wgrad_desc* d);
 int dvd_wgrad_thin(const dvd_wgrad_desc* d, void* stream);
+// Internal: 3 x 3 (x 3) convolutions with 3 (8) input and 64 output channels (conv_thin.hip); d->wq = dvd_conv_thin_image
+int dvd_conv_thin_in_ok(const dvd_conv_desc* d);
+int dvd_conv_thin_in(const dvd_conv_desc* d, void* stream);
 
 static inline int ilog2_exact(int v) {   // host: log2 of a power of two, -1 otherwise
     if (v <= 0 || (v & (v - 1))) return -1;

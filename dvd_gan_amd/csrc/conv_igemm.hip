@@ -2257,7 +2257,7 @@ extern "C" void dvd_prof_enable(int on) {
 // kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Drains the records of `kind` and returns the number of
 // launches; n / ms / flops (each [nvar] or NULL) receive the per-variant totals -- kind 0: 1 = conv_halo 256 x 128,
 // 2 = conv_halo 128 x 128, 3 = conv_halo 256 x 64 (thin outputs), 4 = conv_igemm 128 x 128, 5 = conv_igemm 256 x 128,
-// 6 = conv_igemm 256 x 256 (8 waves), 7 / 8 = whole-frame footprint kernel (4 x 4 / 8 x 8 frames) 256 x 128 / 128 x 128; kind 1: 1 = filter-row kernel, 2 = one-tap kernel, 3 = thin-end kernel (wgrad_thin.hip); index 0 = everything.
+// 6 = conv_igemm 256 x 256 (8 waves), 7 / 8 = whole-frame footprint kernel (4 x 4 / 8 x 8 frames) 256 x 128 / 128 x 128, 9 = thin-input kernel (conv_thin.hip); kind 1: 1 = filter-row kernel, 2 = one-tap kernel, 3 = thin-end kernel (wgrad_thin.hip); index 0 = everything.
 // If the environment variable DVD_PROF_CSV is set, every drained record is appended to that file.
 extern "C" long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops) {
     std::lock_guard<std::mutex> l(g_prof_mu);
@@ -2387,6 +2387,12 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     if (rc != DVD_OK) return rc;
     const long long M = pl.M;
     const bool halo = pl.halo, thin = pl.thin, wide = pl.wide, big = pl.big;
+    if (!g && d->wq && dvd_conv_thin_in_ok(d)) {      // the stems / the RGB layer's backward-data pass: taps folded into K (conv_thin.hip)
+        ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout, d->kt * d->kh * d->kw, 1,
+                       d->relu_in << 1);
+        prof.r.variant = 9;
+        return dvd_conv_thin_in(d, stream);
+    }
     dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
     if (g && p.nsplit > 1 && grid.x > DVD_GRU_TICKETS) return DVD_E_SHAPE;      // one ticket per output tile (the small-frame grid below is no larger)
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
@@ -2635,6 +2641,7 @@ extern "C" int dvd_conv_wants_fragment_major(const dvd_conv_desc* d) {
     if (!t.w) t.w = t.in;                 // (only the geometry matters here)
     t.wq = t.w;                           // "if the image were supplied"
     if (conv_plan(&t, nullptr, p, pl) != DVD_OK) return 0;
+    if (dvd_conv_thin_in_ok(d)) return 2;      // 3 (8) input channels -> 64: wants the image of dvd_conv_thin_image in `wq` instead
     return ((pl.halo || pl.smallf) && d->dtype == DVD_BF16) ? 1 : 0;
 }
 

@@ -129,6 +129,18 @@ def _grid(x, ksize, up2):
     return F_, T, H, W
 
 
+def _thin_image(wpack, kt):
+    """The [tap row][k half][channel block][lane][8] image of a [kt*9][64][8] pack for the thin-input convolution kernel
+    (dvd_conv_thin_image); cached on the pack tensor (packs are rebuilt whenever the weights change)."""
+    img = getattr(wpack, "_thin_img", None)
+    if img is None:
+        n = L.lib().dvd_conv_thin_image_bytes(kt)
+        img = torch.empty(n // 2, dtype=wpack.dtype, device=wpack.device)
+        L.check(L.lib().dvd_conv_thin_image(L.ptr(wpack), L.ptr(img), kt, L.stream()))
+        wpack._thin_img = img
+    return img
+
+
 def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L.ACT_NONE, up2=False,
                  relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None, res_up2=False, wq=None):
     """Direct (nsplit=1) or split-K convolution.  `wpack`: [ntaps][cout][Cp] tensor.  Returns the
@@ -143,10 +155,16 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
     d.kt, d.kh, d.kw = k
     d.up2, d.relu_in, d.nsplit, d.act, d.out_f32 = int(up2), int(relu_in), nsplit, act, int(out_f32)
     d.inp, d.w, d.bias = x.data_ptr(), wpack.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    if res is not None:
+        d.res, d.ldres, d.res_up2 = res.data_ptr(), res.shape[-1], int(res_up2)
+    if mask is not None:
+        d.mask, d.ldmask = mask.data_ptr(), mask.shape[-1]
     if callable(wq):                      # lazily built fragment-major image: only when this request runs through that kernel
         d.nsplit, d.out = max(1, nsplit), 1          # (placeholders for the geometry query; the real pointers are set below)
+        d.ldo = out.shape[-1] if out is not None else (cout_pad or pad8(cout))
         d.ws = 1 if (nsplit > 1 or slabs or ws is not None) else None
-        wq = wq() if (x.dtype == torch.bfloat16 and L.lib().dvd_conv_wants_fragment_major(C.byref(d))) else None
+        want = L.lib().dvd_conv_wants_fragment_major(C.byref(d)) if x.dtype == torch.bfloat16 else 0
+        wq = wq() if want == 1 else _thin_image(wpack, k[0]) if want == 2 else None
     d.wq = wq.data_ptr() if wq is not None else None
     d.out = d.ws = None
     nk = k[0] * k[1] * k[2] * ((Cp + (31 if x.dtype == torch.bfloat16 else 15)) // (32 if x.dtype == torch.bfloat16 else 16))
@@ -163,10 +181,6 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
         alloc = torch.zeros if cp_out != cout else torch.empty
         out = alloc(shape, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d.out, d.ldo = out.data_ptr(), out.shape[-1]
-    if res is not None:
-        d.res, d.ldres, d.res_up2 = res.data_ptr(), res.shape[-1], int(res_up2)
-    if mask is not None:
-        d.mask, d.ldmask = mask.data_ptr(), mask.shape[-1]
     L.check(L.lib().dvd_conv_forward(C.byref(d), L.stream()))
     return out
 

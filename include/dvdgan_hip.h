@@ -43,8 +43,8 @@ void dvd_prof_enable(int on);
 long long dvd_prof_report(int kind, double* total_ms, double* total_flops);
 /* The same, split by kernel variant: n / ms / flops are arrays of nvar entries (or NULL); entry 0 = all launches of `kind`,
  * kind 0: 1 = conv_halo 256x128 tile, 2 = conv_halo 128x128, 3 = conv_halo 256x64, 4 = conv_igemm 128x128,
- * 5 = conv_igemm 256x128, 6 = conv_igemm 256x256, 7 / 8 = whole-frame footprint kernel (4x4 / 8x8 frames) 256x128 / 128x128;
- * kind 1: 1 = filter-row kernel, 2 = one-tap kernel. */
+ * 5 = conv_igemm 256x128, 6 = conv_igemm 256x256, 7 / 8 = whole-frame footprint kernel (4x4 / 8x8 frames) 256x128 / 128x128,
+ * 9 = thin-input kernel (3 -> 64 channels); kind 1: 1 = filter-row kernel, 2 = one-tap kernel, 3 = thin-end kernel. */
 long long dvd_prof_report_variants(int kind, int nvar, long long* n, double* ms, double* flops);
 const char* dvd_strerror(int code);
 
@@ -94,7 +94,12 @@ int dvd_conv_forward(const dvd_conv_desc* d, void* stream);
  * pack of dvd_pack_conv_weight ([ntaps][Cout][C], bf16, C % 8 == 0).  Re-run after every re-pack (spectral norm: every forward). */
 long long dvd_conv_fragment_major_bytes(int ntaps, int Cout, int C);
 int dvd_conv_fragment_major(int dtype, const void* w, void* wq, int ntaps, int Cout, int C, void* stream);
-int dvd_conv_wants_fragment_major(const dvd_conv_desc* d);
+int dvd_conv_wants_fragment_major(const dvd_conv_desc* d);     /* 0 = no, 1 = fragment-major image, 2 = the thin-input image below */
+/* 3 x 3 (x 3) convolutions from 3 (padded to 8) input channels to 64 output channels (the discriminator stems, the backward-data
+ * pass of the RGB layer) fold their KW taps into the K dimension; they take, in `wq`, this image of their [kt*9][64][8] pack:
+ * [tap row][k half][channel block][lane][8] (ABI 10). */
+long long dvd_conv_thin_image_bytes(int kt);
+int dvd_conv_thin_image(const void* w, void* wt, int kt, void* stream);
 
 /* Backward-weight of the same convolution:
  *   dw[co*s_co + ci*s_ci + tap*s_tap] += sum_m dy[m][co] * x[pos(m)+tap][ci]       (fp32 atomics)

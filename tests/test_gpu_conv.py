@@ -165,6 +165,37 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     assert rel(dw2.cpu(), wq_.grad) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(5, (64, 64), (3, 3), True, 1, False), (3, (6, 32, 32), (3, 3, 3), False, 0, False),
+                                  (4, (32, 32), (3, 3), False, 1, True), (2, (4, 64, 64), (3, 3, 3), True, 0, True)])
+def test_thin_input_convolution(case):
+    """3 -> 64 channels in bf16 mode (the discriminator stems; with a mask: the backward-data pass of the RGB layer): the kernel
+    that folds the KW taps into the K dimension (conv_thin.hip), against torch on the bf16-rounded operands and against the
+    halo-staged kernel (no weight image supplied)."""
+    from dvd_gan_amd import kern as K
+    from dvd_gan_amd import lib as L
+    F_, sp, ks, relu_in, act, use_mask = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(F_, 3, *sp, generator=g)
+    w = torch.randn(64, 3, *ks, generator=g) / (3 * ks[-1] * ks[-2]) ** 0.5
+    b = torch.randn(64, generator=g)
+    msk = torch.randn(F_, 64, *sp, generator=g)
+    dev = "cuda"
+    want = ref_conv(bf(x), bf(w), b, False, relu_in)
+    if act:
+        want = F.relu(want)
+    if use_mask:
+        want = want * (bf(msk) > 0)
+    xc = K.to_cl(x.to(dev), torch.bfloat16)
+    mc = K.to_cl(msk.to(dev), torch.bfloat16) if use_mask else None
+    pk = K.PackedConv(torch.bfloat16, 64, 3, ks, dev).fill(w.to(dev))
+    import ctypes as C
+    got = K.conv_forward(xc, pk.wf, ks, 64, bias=b.to(dev), act=act, relu_in=relu_in, mask=mc, wq=lambda: pk.fragment_major("wf"))
+    assert getattr(pk.wf, "_thin_img", None) is not None, "the request should have taken the thin-input kernel"
+    ref = K.conv_forward(xc, pk.wf, ks, 64, bias=b.to(dev), act=act, relu_in=relu_in, mask=mc)
+    assert rel(K.from_cl(got, 64).cpu(), want) < 3e-3
+    assert rel(got.float().cpu(), ref.float().cpu()) < 1e-3       # same operands, fp32 sums in another order, one bf16 rounding
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 16, 40, (16, 16), (3, 3)), (2, 8, 24, (4, 8, 8), (3, 3, 3)), (5, 24, 8, (32, 32), (1, 1)),
                                    (3, 16, 24, (12, 12), (3, 3)), (2, 8, 8, (6, 24), (1, 1))])
