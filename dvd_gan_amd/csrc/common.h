@@ -117,6 +117,8 @@ int dvd_wgrad_thin(const dvd_wgrad_desc* d, void* stream);
 // Internal: 3 x 3 (x 3) convolutions with 3 (8) input and 64 output channels (conv_thin.hip); d->wq = dvd_conv_thin_image
 int dvd_conv_thin_in_ok(const dvd_conv_desc* d);
 int dvd_conv_thin_in(const dvd_conv_desc* d, void* stream);
+int dvd_conv_thin_out_ok(const dvd_conv_desc* d);      // 64 -> 3 (8) channels, 3 x 3; d->wq = dvd_conv_thin_out_image
+int dvd_conv_thin_out(const dvd_conv_desc* d, void* stream);
 
 static inline int ilog2_exact(int v) {   // host: log2 of a power of two, -1 otherwise
     if (v <= 0 || (v & (v - 1))) return -1;

@@ -2393,6 +2393,12 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
         prof.r.variant = 9;
         return dvd_conv_thin_in(d, stream);
     }
+    if (!g && d->wq && dvd_conv_thin_out_ok(d)) {     // the RGB layer / the stems' backward-data pass (conv_thin.hip)
+        ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout, d->kt * d->kh * d->kw, 1,
+                       d->relu_in << 1);
+        prof.r.variant = 9;
+        return dvd_conv_thin_out(d, stream);
+    }
     dim3 grid(cdiv(M, big ? 256 : 128) * p.tilesN, 1, p.nsplit);
     if (g && p.nsplit > 1 && grid.x > DVD_GRU_TICKETS) return DVD_E_SHAPE;      // one ticket per output tile (the small-frame grid below is no larger)
     ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout,
@@ -2642,6 +2648,7 @@ extern "C" int dvd_conv_wants_fragment_major(const dvd_conv_desc* d) {
     t.wq = t.w;                           // "if the image were supplied"
     if (conv_plan(&t, nullptr, p, pl) != DVD_OK) return 0;
     if (dvd_conv_thin_in_ok(d)) return 2;      // 3 (8) input channels -> 64: wants the image of dvd_conv_thin_image in `wq` instead
+    if (dvd_conv_thin_out_ok(d)) return 3;     // 64 -> 3 (8) channels: dvd_conv_thin_out_image
     return ((pl.halo || pl.smallf) && d->dtype == DVD_BF16) ? 1 : 0;
 }
 

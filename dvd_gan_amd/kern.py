@@ -141,6 +141,16 @@ def _thin_image(wpack, kt):
     return img
 
 
+def _thin_out_image(wpack):
+    """The [tap][16-channel step][lane][8] image of a [9][rows <= 8][64] pack for the thin-output convolution kernel."""
+    img = getattr(wpack, "_thin_img", None)
+    if img is None:
+        img = torch.empty(L.lib().dvd_conv_thin_out_image_bytes() // 2, dtype=wpack.dtype, device=wpack.device)
+        L.check(L.lib().dvd_conv_thin_out_image(L.ptr(wpack), L.ptr(img), wpack.shape[1], L.stream()))
+        wpack._thin_img = img
+    return img
+
+
 def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L.ACT_NONE, up2=False,
                  relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None, res_up2=False, wq=None):
     """Direct (nsplit=1) or split-K convolution.  `wpack`: [ntaps][cout][Cp] tensor.  Returns the
@@ -164,7 +174,7 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
         d.ldo = out.shape[-1] if out is not None else (cout_pad or pad8(cout))
         d.ws = 1 if (nsplit > 1 or slabs or ws is not None) else None
         want = L.lib().dvd_conv_wants_fragment_major(C.byref(d)) if x.dtype == torch.bfloat16 else 0
-        wq = wq() if want == 1 else _thin_image(wpack, k[0]) if want == 2 else None
+        wq = wq() if want == 1 else _thin_image(wpack, k[0]) if want == 2 else _thin_out_image(wpack) if want == 3 else None
     d.wq = wq.data_ptr() if wq is not None else None
     d.out = d.ws = None
     nk = k[0] * k[1] * k[2] * ((Cp + (31 if x.dtype == torch.bfloat16 else 15)) // (32 if x.dtype == torch.bfloat16 else 16))

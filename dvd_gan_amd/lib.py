@@ -46,6 +46,7 @@ def lib():
         _lib.dvd_conv_fragment_major_bytes.restype = C.c_longlong
         _lib.dvd_convgru_ws_floats.restype = C.c_longlong
         _lib.dvd_conv_thin_image_bytes.restype = C.c_longlong
+        _lib.dvd_conv_thin_out_image_bytes.restype = C.c_longlong
         if _lib.dvd_abi_version() != ABI_VERSION:
             raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
     return _lib

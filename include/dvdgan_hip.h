@@ -94,12 +94,16 @@ int dvd_conv_forward(const dvd_conv_desc* d, void* stream);
  * pack of dvd_pack_conv_weight ([ntaps][Cout][C], bf16, C % 8 == 0).  Re-run after every re-pack (spectral norm: every forward). */
 long long dvd_conv_fragment_major_bytes(int ntaps, int Cout, int C);
 int dvd_conv_fragment_major(int dtype, const void* w, void* wq, int ntaps, int Cout, int C, void* stream);
-int dvd_conv_wants_fragment_major(const dvd_conv_desc* d);     /* 0 = no, 1 = fragment-major image, 2 = the thin-input image below */
+int dvd_conv_wants_fragment_major(const dvd_conv_desc* d);     /* 0 = no, 1 = fragment-major image, 2 / 3 = the thin-input / thin-output image below */
 /* 3 x 3 (x 3) convolutions from 3 (padded to 8) input channels to 64 output channels (the discriminator stems, the backward-data
  * pass of the RGB layer) fold their KW taps into the K dimension; they take, in `wq`, this image of their [kt*9][64][8] pack:
  * [tap row][k half][channel block][lane][8] (ABI 10). */
 long long dvd_conv_thin_image_bytes(int kt);
 int dvd_conv_thin_image(const void* w, void* wt, int kt, void* stream);
+/* ... and 3 x 3 convolutions from 64 to at most 8 output channels (the RGB layer, the spatial stem's backward-data pass; wants = 3)
+ * this image of their [9][rows][64] pack (rows = output rows present in the pack, <= 8): [tap][16-channel step][lane][8] */
+long long dvd_conv_thin_out_image_bytes(void);
+int dvd_conv_thin_out_image(const void* w, void* wt, int rows, void* stream);
 
 /* Backward-weight of the same convolution:
  *   dw[co*s_co + ci*s_ci + tap*s_tap] += sum_m dy[m][co] * x[pos(m)+tap][ci]       (fp32 atomics)

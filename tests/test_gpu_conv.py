@@ -196,6 +196,41 @@ def test_thin_input_convolution(case):
     assert rel(got.float().cpu(), ref.float().cpu()) < 1e-3       # same operands, fp32 sums in another order, one bf16 rounding
 
 
+@pytest.mark.parametrize("case", [(5, 64, True, 2), (3, 32, False, 0), (2, 64, False, 1)])
+def test_thin_output_convolution(case):
+    """64 -> 3 channels, 3 x 3, bf16 mode (the generator's RGB layer: ReLU -> conv -> tanh) and, on the backward-data pack of a
+    3 -> 64 stem with a ReLU mask, 64 -> 8 (3 real): conv_thin.hip's thin-output kernel against torch on the bf16-rounded operands
+    and against the halo-staged kernel."""
+    from dvd_gan_amd import kern as K
+    F_, S, relu_in, act = case
+    g = torch.Generator().manual_seed(43)
+    dev = "cuda"
+    x = torch.randn(F_, 64, S, S, generator=g)
+    w = torch.randn(3, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(3, generator=g)
+    want = ref_conv(bf(x), bf(w), b, False, relu_in)
+    want = torch.tanh(want) if act == 2 else F.relu(want) if act == 1 else want
+    xc = K.to_cl(x.to(dev), torch.bfloat16)
+    pk = K.PackedConv(torch.bfloat16, 3, 64, (3, 3), dev).fill(w.to(dev))
+    got = K.conv_forward(xc, pk.wf, (3, 3), 3, bias=b.to(dev), act=act, relu_in=relu_in, wq=lambda: pk.fragment_major("wf"))
+    assert getattr(pk.wf, "_thin_img", None) is not None, "the request should have taken the thin-output kernel"
+    ref = K.conv_forward(xc, pk.wf, (3, 3), 3, bias=b.to(dev), act=act, relu_in=relu_in)
+    assert rel(K.from_cl(got, 3).cpu(), want) < 4e-3
+    assert rel(got.float().cpu(), ref.float().cpu()) < 2e-3
+    assert float(got[..., 3:].abs().max()) == 0.0                   # pad channels stay zero
+    # backward-data of a 3 -> 64 stem: dy [.., 64] through the flipped / transposed pack, masked by the stem's input
+    ws = torch.randn(64, 3, 3, 3, generator=g) / 5.0
+    xin = torch.randn(F_, 3, S, S, generator=g)
+    ps = K.PackedConv(torch.bfloat16, 64, 3, (3, 3), dev).fill(ws.to(dev))
+    mc = K.to_cl(xin.to(dev), torch.bfloat16)
+    dx = K.conv_forward(xc, ps.wd, (3, 3), ps.cip, mask=mc, wq=lambda: ps.fragment_major("wd"))
+    assert getattr(ps.wd, "_thin_img", None) is not None
+    dx_ref = K.conv_forward(xc, ps.wd, (3, 3), ps.cip, mask=mc)
+    wdx = torch.nn.functional.conv_transpose2d(bf(x), bf(ws), padding=1) * (bf(xin) > 0)
+    assert rel(K.from_cl(dx, 3).cpu(), wdx) < 4e-3
+    assert rel(dx.float().cpu(), dx_ref.float().cpu()) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 16, 40, (16, 16), (3, 3)), (2, 8, 24, (4, 8, 8), (3, 3, 3)), (5, 24, 8, (32, 32), (1, 1)),
                                    (3, 16, 24, (12, 12), (3, 3)), (2, 8, 8, (6, 24), (1, 1))])
