@@ -2387,13 +2387,14 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     if (rc != DVD_OK) return rc;
     const long long M = pl.M;
     const bool halo = pl.halo, thin = pl.thin, wide = pl.wide, big = pl.big;
-    if (!g && d->wq && dvd_conv_thin_in_ok(d)) {      // the stems / the RGB layer's backward-data pass: taps folded into K (conv_thin.hip)
+    if (d->wq_kind >= 2 && !(d->wq_kind == 2 ? dvd_conv_thin_in_ok(d) : dvd_conv_thin_out_ok(d))) return DVD_E_ARG;   // a thin image the request cannot use
+    if (!g && d->wq && d->wq_kind == 2 && dvd_conv_thin_in_ok(d)) {      // the stems / the RGB layer's backward-data pass: taps folded into K (conv_thin.hip)
         ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout, d->kt * d->kh * d->kw, 1,
                        d->relu_in << 1);
         prof.r.variant = 9;
         return dvd_conv_thin_in(d, stream);
     }
-    if (!g && d->wq && dvd_conv_thin_out_ok(d)) {     // the RGB layer / the stems' backward-data pass (conv_thin.hip)
+    if (!g && d->wq && d->wq_kind == 3 && dvd_conv_thin_out_ok(d)) {     // the RGB layer / the stems' backward-data pass (conv_thin.hip)
         ProfScope prof(0, 2.0 * (double)M * d->Cout * d->C * d->kt * d->kh * d->kw, stream, M, d->C, d->Cout, d->kt * d->kh * d->kw, 1,
                        d->relu_in << 1);
         prof.r.variant = 9;

@@ -175,6 +175,7 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
         d.ws = 1 if (nsplit > 1 or slabs or ws is not None) else None
         want = L.lib().dvd_conv_wants_fragment_major(C.byref(d)) if x.dtype == torch.bfloat16 else 0
         wq = wq() if want == 1 else _thin_image(wpack, k[0]) if want == 2 else _thin_out_image(wpack) if want == 3 else None
+        d.wq_kind = want if wq is not None else 0
     d.wq = wq.data_ptr() if wq is not None else None
     d.out = d.ws = None
     nk = k[0] * k[1] * k[2] * ((Cp + (31 if x.dtype == torch.bfloat16 else 15)) // (32 if x.dtype == torch.bfloat16 else 16))

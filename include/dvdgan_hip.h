@@ -87,6 +87,8 @@ typedef struct {
                                   (dvd_conv_fragment_major); requests for which
                                   dvd_conv_wants_fragment_major() is 1 then read their weight operand
                                   straight from L2 into registers instead of staging it in LDS       */
+    int wq_kind;               /* what `wq` holds: 0 / 1 = the fragment-major image, 2 = dvd_conv_thin_image, 3 = dvd_conv_thin_out_image
+                                  (the value dvd_conv_wants_fragment_major returned for this request) */
 } dvd_conv_desc;
 int dvd_conv_forward(const dvd_conv_desc* d, void* stream);
 /* Fragment-major weight image: [tap][32-channel chunk][32-column block, padded to whole 128-column tiles][k-half pair][lane]
