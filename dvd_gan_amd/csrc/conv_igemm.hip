@@ -2365,7 +2365,12 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
     static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;
-    const bool big = wide || cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= big_thr;   // >= 2 workgroups per CU
+    // 1 x 1 filters are HBM-bound streams with 2-8 K steps: the 256-row tap-by-tap tile holds 433 registers = ONE workgroup per CU, the
+    // 128-row tile 240 = two.  3.1 M x 128 -> 128: 665 -> 505 us, 128 -> 64: 691 -> 420, 64 -> 128: 574 -> 422; step 493.4 -> 490.9 ms
+    // (DVD_CONV_BIG1 = 1 restores the 256-row tile)
+    static const int big1 = getenv("DVD_CONV_BIG1") ? atoi(getenv("DVD_CONV_BIG1")) : 0;
+    const bool one_tap = d->kt * d->kh * d->kw == 1 && !halo && !smallf;
+    const bool big = wide || (cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= big_thr && !(one_tap && !big1));   // >= 2 workgroups per CU
     p.pm = 0;
     {   // pixel-major row order for the tap-by-tap kernel on small frames: the rows of a tile must share their image line
         static const int use_pm = getenv("DVD_CONV_PIXMAJOR") ? atoi(getenv("DVD_CONV_PIXMAJOR")) : 1;
