@@ -1,0 +1,871 @@
+// Weight gradients of the convolutions: conv_wgrad_row_kernel (one filter row per workgroup, 3 x 3 / 5 x 5 / 3 x 3 x 3) and
+// conv_wgrad_kernel (one tap per workgroup: 1 x 1, upsampling and exact-mode convolutions), their fixed-order reduce kernels,
+// and the C ABI entry dvd_conv_wgrad.
+#include "conv_common.h"
+#include "prof.h"
+#include <cstdlib>
+
+namespace {
+
+// ============================================================================ backward-weight
+struct WgK {
+    const char* x; const char* dy; float* dw;
+    int M, C, ldx, Cin_real, Cout, Cy, ldy;
+    int T, H, W, logH, logW, Hin, Win;
+    int kt, kh, kw, up2, relu_in;
+    int tiles_co, tiles_ci, rows_per_split;
+    long long s_co, s_ci, s_tap;
+    size_t x_bytes, dy_bytes;
+    int maxshift, xcd_remap;
+    float* dbias;
+    float* wsb;             // row kernel, workspace path: bias partial sums [slice][workgroup][BMc] behind the tile partials
+    float* ws;                           // partial tiles [slice][x-block][BMc*BNc] when non-null
+};
+
+// D[co][ci] = sum over rows m of dy[m][co] * x[pos(m)+tap][ci].  The reduction index (rows) is the
+// MFMA K dimension, so both operand tiles must be K(row)-contiguous per channel in LDS:
+//   bf16: tiles are staged in their natural [row][channel] image with 16-byte loads and the
+//         fragments are built by the LDS transpose read ds_read_b64_tr_b16;
+//   f32 : the natural [row][channel] image already matches the 32x32x2 fragment (1 float/lane).
+template <typename T, int TA, int TB>      // wave tile (TA*32 out-channels) x (TB*32 in-channels); block = 2 x 2 waves
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
+    constexpr bool kBf16 = sizeof(T) == 2;
+    static_assert(kBf16 || (TA == 2 && TB == 2), "exact mode uses the 128 x 128 tile");
+    constexpr int BKW = kBf16 ? 32 : 16;            // rows reduced per step
+    constexpr int BMc = TA * 64, BNc = TB * 64;     // block tile: out-channels x in-channels
+    constexpr int RSA = BMc * 2 + 64, RSB = BNc * 2 + 64;          // bf16 LDS row strides (bytes)
+    constexpr int TA_BYTES = kBf16 ? 32 * RSA : TILEB, TB_BYTES = kBf16 ? 32 * RSB : TILEB;
+    __shared__ __attribute__((aligned(16))) char smem[2][TA_BYTES + TB_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware order over (x, z): each XCD gets a contiguous run of row slices, whose workgroups (all
+    // taps / channel tiles of a slice) then share the slice's rows in that XCD's L2 (hit rate 0.42 -> 0.73
+    // on the 3x3 shapes, 0.81 -> 0.89 on the 5x5 ones; tools/pmc_l2.txt)
+    int bx = blockIdx.x, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, total = gx * gridDim.z, lin = bx + gx * bz;
+        const int xcd = lin & 7, qd = total >> 3, rr = total & 7;
+        const int lp = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (lin >> 3);
+        bz = lp / gx; bx = lp - bz * gx;
+    }
+    const int tiles = p.tiles_co * p.tiles_ci;
+    const int tap = bx / tiles;
+    const int rem = bx - tap * tiles;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co0 = tco * BMc, ci0 = tci * BNc;
+    const int it = tap / (p.kh * p.kw), r2 = tap - it * p.kh * p.kw;
+    const int iy = r2 / p.kw, ix = r2 - iy * p.kw;
+    const int dt = it - (p.kt >> 1), dy_ = iy - (p.kh >> 1), dx = ix - (p.kw >> 1);
+    const int m_begin = bz * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    f32x16 acc[TA][TB];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc[a][b] = zacc;
+    }
+
+    // Buffer descriptors: invalid rows / channels use offset 0xFFFFFFFF -> hardware returns zeros.
+    // (32-bit offsets relative to the first row this workgroup's row slice can touch: tensors > 4 GiB ok)
+    constexpr unsigned ESZ = sizeof(T);
+    const int xbase_row = p.up2 ? (m_begin / (p.H * p.W)) * p.Hin * p.Win : max(0, m_begin - p.maxshift);
+    const size_t xbase_b = (size_t)xbase_row * p.ldx * ESZ, ybase_b = (size_t)m_begin * p.ldy * ESZ;
+    const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + xbase_b), 0, xleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)xleft, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ybase_b), 0, yleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)yleft, 0x00020000);
+    // Byte offset of the shifted x row for output row m.  Without upsampling the input grid equals
+    // the output grid, so the shifted row is simply m + delta.
+    const int delta = (dt * p.H + dy_) * p.W + dx;
+    auto xoff = [&](int m, unsigned chan_bytes, bool cvalid) __attribute__((always_inline)) -> unsigned {
+        int fm, ym, xm;
+        grid_pos(m, p.H, p.W, p.logH, p.logW, fm, ym, xm);
+        const int xx = xm + dx, yy = ym + dy_;
+        int tt = dt;
+        if (p.kt > 1) tt += fm % p.T;
+        const bool ok = cvalid && m < m_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W &&
+                        (unsigned)tt < (unsigned)p.T;
+        int row = m + delta;
+        if (p.up2) row = ((fm + dt) * p.Hin + (yy >> 1)) * p.Win + (xx >> 1);
+        return ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * ESZ) + chan_bytes : 0xffffffffu;
+    };
+    auto yoff = [&](int m, unsigned chan_bytes, bool cvalid) __attribute__((always_inline)) -> unsigned {
+        return (cvalid && m < m_end) ? (unsigned)(m - m_begin) * ((unsigned)p.ldy * ESZ) + chan_bytes : 0xffffffffu;
+    };
+
+    if constexpr (kBf16) {
+        // Natural [row][channel] LDS image (row stride 320 B = 256 B of channels + 64 B: the four
+        // rows a 16-lane group touches land on disjoint bank quarters).  MFMA fragments need 8
+        // consecutive ROWS of one channel per lane: ds_read_b64_tr_b16 delivers exactly that
+        // (each 16-lane group reads a 4-row x 16-channel block and hands lane i column i).
+        // operand A = dy (BMc channels per row), operand B = x (BNc channels per row)
+        constexpr int CPRA = BMc / 8, RPPA = NT / CPRA, NPA = 32 / RPPA;       // chunks/row, rows/pass, passes
+        constexpr int CPRB = BNc / 8, RPPB = NT / CPRB, NPB = 32 / RPPB;
+        const int rra = tid / CPRA, cka = tid % CPRA, rrb = tid / CPRB, ckb = tid % CPRB;
+        const int cy = co0 + cka * 8, cx = ci0 + ckb * 8;
+        const bool cyv = cy < p.Cy, cxv = cx < p.C;
+        u32x4 ra[NPA], rb[NPB];
+        auto wg_gload = [&](int mk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i)
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, yoff(mk + rra + i * RPPA, cy * 2, cyv), 0, 0);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + rrb + i * RPPB, cx * 2, cxv), 0, 0);
+        };
+        // fused bias gradient: the centre-tap / first-ci-tile workgroups sum the dy chunks they stage
+        const bool do_bias = p.dbias != nullptr && dt == 0 && dy_ == 0 && dx == 0 && tci == 0;
+        float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto wg_lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                *reinterpret_cast<u32x4*>(&smem[buf][(rra + i * RPPA) * RSA + cka * 16]) = ra[i];
+                if (do_bias) {
+                    bs[0] += __uint_as_float(ra[i].x << 16); bs[1] += __uint_as_float(ra[i].x & 0xffff0000u);
+                    bs[2] += __uint_as_float(ra[i].y << 16); bs[3] += __uint_as_float(ra[i].y & 0xffff0000u);
+                    bs[4] += __uint_as_float(ra[i].z << 16); bs[5] += __uint_as_float(ra[i].z & 0xffff0000u);
+                    bs[6] += __uint_as_float(ra[i].w << 16); bs[7] += __uint_as_float(ra[i].w & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+                *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + (rrb + i * RPPB) * RSB + ckb * 16]) =
+                    p.relu_in ? relu16_bf16(rb[i]) : rb[i];
+        };
+#define WG_GLOAD(mk) wg_gload(mk)
+#define WG_LSTORE(buf) wg_lstore(buf)
+        // per-lane offset of its 8-byte chunk inside a 4-row x 16-channel block of a fragment:
+        // rows (g16>>1)*8 + (i16>>2), channels (g16&1)*16 + (i16&3)*4
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int frow = (g16 >> 1) * 8 + (i16 >> 2), fcol2 = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;
+        auto frag = [&](const char* tile, int rs, int col0, int kb) __attribute__((always_inline)) -> bf16x8 {
+            typedef __attribute__((ext_vector_type(4))) short s16x4;
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const char* pz = tile + (frow + kb) * rs + fcol2 + col0 * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pz);
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pz + 4 * rs));
+            s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(bf16x8, f);
+        };
+        auto mma = [&](int buf) __attribute__((always_inline)) {
+            const char* At = &smem[buf][0];
+            const char* Bt = &smem[buf][TA_BYTES];
+            // all fragment reads of the 32-row step are issued up front: the second half's transpose
+            // reads land while the first half's MFMAs run
+            bf16x8 fa0[TA], fb0[TB], fa1[TA], fb1[TB];
+#pragma unroll
+            for (int a = 0; a < TA; ++a) fa0[a] = frag(At, RSA, wm * (TA * 32) + a * 32, 0);
+#pragma unroll
+            for (int b = 0; b < TB; ++b) fb0[b] = frag(Bt, RSB, wn * (TB * 32) + b * 32, 0);
+#pragma unroll
+            for (int a = 0; a < TA; ++a) fa1[a] = frag(At, RSA, wm * (TA * 32) + a * 32, 16);
+#pragma unroll
+            for (int b = 0; b < TB; ++b) fb1[b] = frag(Bt, RSB, wn * (TB * 32) + b * 32, 16);
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[a], fb0[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[a], fb1[b], acc[a][b], 0, 0, 0);
+        };
+        if (m_begin < m_end) {
+            WG_GLOAD(m_begin);
+            WG_LSTORE(0);
+            __syncthreads();
+            int buf = 0;
+            for (int mk = m_begin; mk < m_end; mk += BKW, buf ^= 1) {
+                const bool more = mk + BKW < m_end;
+                if (more) WG_GLOAD(mk + BKW);
+                mma(buf);
+                if (more) WG_LSTORE(buf ^ 1);
+                __syncthreads();
+            }
+        }
+#undef WG_GLOAD
+#undef WG_LSTORE
+        if (do_bias) {                                   // threads sharing a channel chunk: rra = 0..RPPA-1
+            float* red = reinterpret_cast<float*>(&smem[0][0]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
+            __syncthreads();
+            if (tid < CPRA) {
+                for (int k = 0; k < 8; ++k) {
+                    float a = 0.f;
+                    for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
+                    const int co = co0 + tid * 8 + k;
+                    if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // f32: LDS image [16 rows][WG_LD floats]; thread stages rows kr, kr+8, 16-byte chunk ch
+        const int ch = tid & 31, kr = tid >> 5;
+        const int cy = co0 + ch * 4, cx = ci0 + ch * 4;
+        const bool cyv = cy < p.Cy, cxv = cx < p.C;
+        u32x4 a0, a1, b0, b1;
+        auto gload = [&](int mk) __attribute__((always_inline)) {
+            a0 = __builtin_amdgcn_raw_buffer_load_b128(rdy, yoff(mk + kr, cy * 4, cyv), 0, 0);
+            a1 = __builtin_amdgcn_raw_buffer_load_b128(rdy, yoff(mk + kr + 8, cy * 4, cyv), 0, 0);
+            b0 = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + kr, cx * 4, cxv), 0, 0);
+            b1 = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff(mk + kr + 8, cx * 4, cxv), 0, 0);
+        };
+        const bool do_bias = p.dbias != nullptr && dt == 0 && dy_ == 0 && dx == 0 && tci == 0;
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
+        auto lstore = [&](int buf) __attribute__((always_inline)) {
+            if (do_bias) {
+                bs[0] += __uint_as_float(a0.x) + __uint_as_float(a1.x); bs[1] += __uint_as_float(a0.y) + __uint_as_float(a1.y);
+                bs[2] += __uint_as_float(a0.z) + __uint_as_float(a1.z); bs[3] += __uint_as_float(a0.w) + __uint_as_float(a1.w);
+            }
+            *reinterpret_cast<u32x4*>(&smem[buf][(kr * WG_LD + ch * 4) * 4]) = a0;
+            *reinterpret_cast<u32x4*>(&smem[buf][((kr + 8) * WG_LD + ch * 4) * 4]) = a1;
+            *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + (kr * WG_LD + ch * 4) * 4]) = p.relu_in ? relu16_f32(b0) : b0;
+            *reinterpret_cast<u32x4*>(&smem[buf][TA_BYTES + ((kr + 8) * WG_LD + ch * 4) * 4]) = p.relu_in ? relu16_f32(b1) : b1;
+        };
+        auto mma = [&](int buf) {
+            const float* As = reinterpret_cast<const float*>(&smem[buf][0]) + wm * 64 + (lane & 31);
+            const float* Bs = reinterpret_cast<const float*>(&smem[buf][TA_BYTES]) + wn * 64 + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = kk * 2 + (lane >> 5);
+                const float a0 = As[k * WG_LD], a1 = As[k * WG_LD + 32];
+                const float b0 = Bs[k * WG_LD], b1 = Bs[k * WG_LD + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        };
+        if (m_begin < m_end) {
+            gload(m_begin);
+            lstore(0);
+            __syncthreads();
+            int buf = 0;
+            for (int mk = m_begin; mk < m_end; mk += BKW, buf ^= 1) {
+                const bool more = mk + BKW < m_end;
+                if (more) gload(mk + BKW);
+                mma(buf);
+                if (more) lstore(buf ^ 1);
+                __syncthreads();
+            }
+        }
+        if (do_bias) {                                   // threads sharing a channel chunk: kr = 0..7
+            float* red = reinterpret_cast<float*>(&smem[0][0]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[tid * 4 + k] = bs[k];
+            __syncthreads();
+            if (tid < 32) {
+                for (int k = 0; k < 4; ++k) {
+                    float a = 0.f;
+                    for (int r = 0; r < 8; ++r) a += red[(r * 32 + tid) * 4 + k];
+                    const int co = co0 + tid * 4 + k;
+                    if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // epilogue: each 32x32 accumulator tile goes through a per-wave LDS block and is then added to
+    // dw with a rolled loop (an unrolled 128-atomic epilogue costs ~170 VGPRs of addresses)
+    float* ep = reinterpret_cast<float*>(&smem[0][0]) + wave * (32 * 32);
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[ta][tb][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int ci = ci0 + wn * (TB * 32) + tb * 32 + (lane & 31);
+            const int cob = co0 + wm * (TA * 32) + ta * 32 + (lane >> 5);
+            float* dst = p.dw + ci * p.s_ci + tap * p.s_tap;
+            if (p.ws) {
+                // partial tile of this row slice, tile-local [row][col] layout, coalesced plain stores
+                float* wt = p.ws + ((size_t)bz * gridDim.x + bx) * (size_t)(BMc * BNc) +
+                            (size_t)(wm * (TA * 32) + ta * 32) * BNc + wn * (TB * 32) + tb * 32;
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j)
+                    wt[(size_t)(2 * j + (lane >> 5)) * BNc + (lane & 31)] = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+            } else if (ci < p.Cin_real) {
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j) {
+                    const int co = cob + 2 * j;
+                    const float v = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+                    if (co < p.Cout && v != 0.f) atomicAdd(dst + co * p.s_co, v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// ============================================================================ backward-weight, one filter ROW per workgroup
+// Same contraction as conv_wgrad_kernel, regrouped so the staged operands are reused across taps: a workgroup owns
+// (filter row iy, 64*WM out-channels, 64 in-channels) and ALL KW taps of that row.  Per 32-pixel step it stages
+// the dy rows once and the input FOOTPRINT of the step -- the 32 pixels plus KW-1 halo columns (two 16-pixel lines
+// when W = 16) -- once; the B fragment of tap ix is the same footprint read ix rows further on.  Bytes staged per
+// MFMA drop from 384 (256 x 128 tile, one tap) to ~130, and dy / x are fetched from L2 KH instead of KH*KW times.
+//   waves: WM (64 out-channels each) x 2 (32 in-channels each); wave tile 64 x (KW taps x 32) = 2 x KW accumulators
+//   LDS:   dy [32 rows][64*WM ch] (+64 B pad, transposing reads as in conv_wgrad_kernel);
+//          x  [2 halves of 32 ch][48 rows][64 B]: the 4 consecutive rows a ds_read_b64_tr_b16 pass touches are
+//             256 contiguous bytes (conflict-free without a swizzle) and a tap is a +64-byte immediate offset.
+// UP2: the convolution reads a nearest-x2 upsampled input (GResBlock.py:57-58): the footprint is kept in INPUT
+// coordinates (half the columns), tap ix of step pixel pk reads row ((pk + ix - pad) >> 1) + 1 of it.
+// 3 x 3 filters stay near 0.9 PF/s: with three taps per row the LDS is the limit, not the staging traffic -- per stage of the
+// 256-channel tile 640 cycles of fragment reads + 624 of ds_write_b128 (13 cycles each) against 1536 MFMA cycles, 82 % busy
+// (5 taps: 59 %).  A nine-tap variant (128 x 64 channel tile, dy staged once for all three filter rows, 146 staged bytes per
+// MFMA instead of 212) was built and passed the tests: +3 % on 786 k x 256 -> 256, -2 % on 3.1 M x 128 -> 128 (its 10 fragment
+// reads per 9 MFMAs keep the LDS as busy); removed.
+// NH: 32-channel blocks of input channels per workgroup (2 = 64 channels; 4 = 128, used with WM = 2 so that the 128-channel
+// output tile also runs as ONE 8-wave workgroup per CU and can stagger its two halves, see the main loop).
+template <int WM, int KW, bool RELU, bool UP2 = false, int NH = 2>
+__global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
+    constexpr int NWAVE = WM * NH, NTt = NWAVE * 64, BMc = WM * 64, BNc = NH * 32;
+    constexpr int RSA = BMc * 2 + 64;
+    constexpr int TA_BYTES = 32 * RSA;
+    constexpr int XROWS = KW == 5 ? 64 : 48, XHALF = XROWS * 64, TB_BYTES = NH * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows; W = 4: 8 lines x 8 (6) rows
+    constexpr int NS = 2;      // 32-pixel sub-steps per barrier (3x3: 0.72 -> 0.80 PF/s, 5x5: +3 %; three sub-steps cost occupancy)
+    constexpr int SUB = TA_BYTES + TB_BYTES, STAGE = NS * SUB;
+    constexpr int EPIB = NWAVE * 32 * 32 * 4;
+    constexpr int REDB = NTt * 8 * 4;                            // bias partial sums
+    constexpr int LDSB = 2 * STAGE > EPIB ? (2 * STAGE > REDB ? 2 * STAGE : REDB) : (EPIB > REDB ? EPIB : REDB);
+    __shared__ __attribute__((aligned(16))) char smem[LDSB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NH, wn = wave % NH;
+    int bx = blockIdx.x, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, total = gx * gridDim.z, lin = bx + gx * bz;
+        const int xcd = lin & 7, qd = total >> 3, rr = total & 7;
+        const int lp = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (lin >> 3);
+        bz = lp / gx; bx = lp - bz * gx;
+    }
+    const int tiles = p.tiles_co * p.tiles_ci;
+    const int irow = bx / tiles;                                 // filter row index: it * kh + iy
+    const int rem = bx - irow * tiles;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co0 = tco * BMc, ci0 = tci * BNc;
+    constexpr int pad = KW >> 1;
+    const int it = irow / KW, iy = irow - it * KW;               // kh == kw
+    const int dyl = iy - pad, dtl = it - (p.kt >> 1);
+    const int m_begin = bz * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    f32x16 acc[2][KW];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < KW; ++t) acc[a][t] = zacc;
+    }
+    const int xbase_row = UP2 ? (m_begin >> (p.logW + p.logH)) * p.Hin * p.Win : max(0, m_begin - p.maxshift);
+    const size_t xbase_b = (size_t)xbase_row * p.ldx * 2, ybase_b = (size_t)m_begin * p.ldy * 2;
+    const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + xbase_b), 0, xleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)xleft, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ybase_b), 0, yleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)yleft, 0x00020000);
+    // step geometry: 32 pixels = one 32-pixel segment of a line (W >= 32), two 16-pixel lines or four 8-pixel lines
+    constexpr int cpad = (pad + 1) >> 1;
+    const int segw = min(p.W, 32), logsegw = min(p.logW, 5);
+    const int fpr = UP2 ? (segw >> 1) + 2 : segw + KW - 1, frows = (32 >> logsegw) * fpr;
+    // dy loader: NPA 16-byte chunks per thread
+    constexpr int CPRA = BMc / 8, RPPA = NTt / CPRA, NPA = 32 / RPPA;
+    const int rra = tid / CPRA, cka = tid % CPRA;
+    const int cy = co0 + cka * 8;
+    const bool cyv = cy < p.Cy;
+    // x footprint loader: XROWS * CPX 16-byte chunks over NTt threads
+    constexpr int CPX = NH * 4;
+    constexpr int NXL = (XROWS * CPX + NTt - 1) / NTt;
+    int xseg[NXL], xj[NXL], xdst[NXL];
+    unsigned xcb[NXL];
+    bool xcv[NXL];
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+        const int q = tid + i * NTt, row = q / CPX, c8 = q % CPX;
+        xseg[i] = row / fpr;
+        xj[i] = row - xseg[i] * fpr;
+        const int cx = ci0 + c8 * 8;
+        xcv[i] = row < frows && cx < p.C;
+        xcb[i] = (unsigned)cx * 2;
+        xdst[i] = q < XROWS * CPX ? (c8 >> 2) * XHALF + row * 64 + (c8 & 3) * 16 : -1;
+    }
+    u32x4 ra[NS][NPA], rb[NS][NXL];
+    auto gload1 = [&](int mk, u32x4 (&ra)[NPA], u32x4 (&rb)[NXL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int m = mk + rra + i * RPPA;
+            const unsigned off = (cyv && m < m_end) ? (unsigned)(m - m_begin) * ((unsigned)p.ldy * 2) + cy * 2 : 0xffffffffu;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+        }
+        const int x0 = mk & (p.W - 1), y = (mk >> p.logW) & (p.H - 1);
+        int frow0 = mk - (y << p.logW) - x0;                       // first row of the frame
+        bool tok = mk < m_end;
+        if (p.kt > 1) {                                            // 3-D: the footprint comes from frame t + dt
+            const int tt = (mk >> (p.logW + p.logH)) % p.T + dtl;
+            tok = tok && (unsigned)tt < (unsigned)p.T;
+            frow0 += dtl << (p.logW + p.logH);
+        }
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            // output line the tap row looks at.  A 32-pixel step of 4 x 4 frames spans TWO frames (8 lines): line y + xseg of the
+            // step is line (.. & (H-1)) of frame (.. >> logH) counted from the step's first frame
+            const int lf = y + xseg[i], fo = lf >> p.logH;
+            const int yy = (lf & (p.H - 1)) + dyl;
+            bool ok = xcv[i] && tok && (unsigned)yy < (unsigned)p.H;
+            int row;
+            if (UP2) {
+                const int xin = (x0 >> 1) - cpad + xj[i];
+                ok = ok && (unsigned)xin < (unsigned)p.Win;
+                row = ((mk >> (p.logW + p.logH)) + fo) * (p.Hin * p.Win) + (yy >> 1) * p.Win + xin;
+            } else {
+                const int xx = x0 + xj[i] - pad;
+                ok = ok && (unsigned)xx < (unsigned)p.W;
+                row = frow0 + (fo << (p.logW + p.logH)) + (yy << p.logW) + xx;
+            }
+            const unsigned off = ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i] : 0xffffffffu;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+        }
+    };
+    auto gload = [&](int mk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) gload1(mk + 32 * s_, ra[s_], rb[s_]);
+    };
+    // Bias gradient = column sums of dy.  The dy tile is tap-independent, so ANY workgroup of a (tco, slice) can sum any of its
+    // 32-pixel sub-steps.  With the slice workspace the KW * tiles_ci workgroups of the centre time slab take the sub-steps in turn
+    // (sub-step n belongs to share n % nshare) and leave their partial sums in the workspace for wgrad_row_bias_reduce_kernel:
+    // when only the centre-row, tci == 0 workgroups summed -- every sub-step, ~16 VALU per 16-byte chunk beside their MFMAs -- they
+    // were the stragglers of the launch (+6...11 % on the large shapes), and their atomics formed one chain per channel.
+    const bool spread = p.ws != nullptr;
+    const bool do_bias = p.dbias != nullptr && dtl == 0 && (spread || (dyl == 0 && tci == 0));
+    const int nshare = spread ? KW * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
+    int bphase = 0;                                              // share of the next sub-step to be stored
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto lstore1 = [&](char* st, const u32x4 (&ra)[NPA], const u32x4 (&rb)[NXL]) __attribute__((always_inline)) {
+        const bool mine = do_bias && bphase == myshare;          // wave-uniform
+        if (++bphase == nshare) bphase = 0;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            *reinterpret_cast<u32x4*>(st + (rra + i * RPPA) * RSA + cka * 16) = ra[i];
+            if (mine) {
+                bs[0] += __uint_as_float(ra[i].x << 16); bs[1] += __uint_as_float(ra[i].x & 0xffff0000u);
+                bs[2] += __uint_as_float(ra[i].y << 16); bs[3] += __uint_as_float(ra[i].y & 0xffff0000u);
+                bs[4] += __uint_as_float(ra[i].z << 16); bs[5] += __uint_as_float(ra[i].z & 0xffff0000u);
+                bs[6] += __uint_as_float(ra[i].w << 16); bs[7] += __uint_as_float(ra[i].w & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NXL; ++i)
+            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(st + TA_BYTES + xdst[i]) = RELU ? relu16_bf16(rb[i]) : rb[i];
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) lstore1(&smem[buf * STAGE + s_ * SUB], ra[s_], rb[s_]);
+    };
+    // fragment addressing (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-channel block)
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int frow = (g16 >> 1) * 8 + (i16 >> 2), fcol2 = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;
+    auto tr2 = [&](const char* lo_, const char* hi_) __attribute__((always_inline)) -> bf16x8 {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_);
+        s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, f);
+    };
+    // footprint row of step pixel pk (before the tap offset): line s of a multi-line step starts at row s * fpr
+    constexpr int NT_ = UP2 ? KW : 1;                            // x2 fold: the row depends on the tap's parity
+    int xoffs[2][2][NT_];                                        // [k half][lo / hi 4-row block][tap]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int t = 0; t < NT_; ++t) {
+                const int pk = kb * 16 + frow + hl * 4;
+                const int px_ = pk & (segw - 1);
+                const int fr = (pk >> logsegw) * fpr + (UP2 ? ((px_ + t - pad) >> 1) + cpad : px_);
+                xoffs[kb][hl][t] = TA_BYTES + wn * XHALF + fr * 64 + fcol2;
+            }
+    const int aoff = frow * RSA + fcol2 + (wm * 64) * 2;
+    auto mma1 = [&](const char* st) __attribute__((always_inline)) {
+        constexpr int NU = 2 * KW;                               // units: (k half, tap), 2 MFMAs each
+        bf16x8 fa[2][2], fb[NU];
+        auto ldA = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const char* pz = st + aoff + kb * 16 * RSA + a * 64;
+                fa[kb][a] = tr2(pz, pz + 4 * RSA);
+            }
+        };
+        auto ldB = [&](int u) __attribute__((always_inline)) {
+            const int kb = u / KW, t = u % KW;
+            if constexpr (UP2) fb[u] = tr2(st + xoffs[kb][0][t], st + xoffs[kb][1][t]);
+            else fb[u] = tr2(st + xoffs[kb][0][0] + t * 64, st + xoffs[kb][1][0] + t * 64);
+        };
+        ldA(0); ldB(0); ldB(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + 2 < NU) ldB(u + 2);
+            if (u == KW - 2) ldA(1);
+            const int kb = u / KW, t = u % KW;
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][0], fb[u], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][1], fb[u], acc[1][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) mma1(&smem[buf * STAGE + s_ * SUB]);
+    };
+    if (m_begin < m_end) {
+        // One 8-wave workgroup per CU: waves w and w+4 share a SIMD and would run their load-issue / MFMA / LDS-store phases in
+        // lockstep, leaving the matrix pipe idle while both issue memory operations.  The upper half of the waves therefore
+        // works one stage further ahead in registers and does its LDS stores and global loads BETWEEN the two sub-steps, while
+        // the lower half does them at the stage boundaries: 1.16 -> 1.29 PF/s (5 x 5), 0.86 -> 0.92 (3 x 3, 256-channel tile).
+        // Measured alternatives: loads / stores compiled out 1.41 / 1.58 PF/s; both halves one stage ahead (stores at the top
+        // of the stage) -1.3 %; LDS-DMA staging in a 3-stage ring (no registers, no ds_write; swizzled unpadded rows) 1.13 PF/s,
+        // 1.22 staggered: a `buffer_load ... lds` costs more issue time beside MFMAs than a register load plus its ds_write.
+        const bool late = NWAVE == 8 && NS == 2 && wave >= 4;
+        gload(m_begin);
+        lstore(0);
+        if (late) gload(m_begin + 32 * NS);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        int buf = 0;
+        for (int mk = m_begin; mk < m_end; mk += 32 * NS, buf ^= 1) {
+            if (!late) {
+                gload(mk + 32 * NS);              // past the slice: out-of-range offsets -> zeros
+                mma(buf);
+                lstore(buf ^ 1);
+            } else {
+                mma1(&smem[buf * STAGE]);
+                lstore(buf ^ 1);
+                gload(mk + 2 * 32 * NS);
+                mma1(&smem[buf * STAGE + (NS - 1) * SUB]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): the upper half still has a prefetch in flight
+    }
+    if (do_bias) {
+        float* red = reinterpret_cast<float*>(&smem[0]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
+        __syncthreads();
+        if (tid < CPRA) {
+            for (int k = 0; k < 8; ++k) {
+                float a = 0.f;
+                for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
+                const int co = co0 + tid * 8 + k;
+                if (spread) p.wsb[((size_t)bz * gridDim.x + bx) * BMc + tid * 8 + k] = a;      // partial of (slice, workgroup)
+                else if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: 32 x 32 accumulator tiles through a per-wave LDS block
+    float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 32);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[a][t][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int ci = ci0 + wn * 32 + (lane & 31);
+            const int cob = co0 + wm * 64 + a * 32 + (lane >> 5);
+            const int tap = irow * KW + t;
+            if (p.ws) {
+                // partial tile of this row slice: [slice][x-block][tap of the row][BMc][BNc], plain coalesced stores
+                float* wt = p.ws + (((size_t)bz * gridDim.x + bx) * KW + t) * (size_t)(BMc * BNc) +
+                            (size_t)(wm * 64 + a * 32) * BNc + wn * 32;
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j)
+                    wt[(size_t)(2 * j + (lane >> 5)) * BNc + (lane & 31)] = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+            } else if (ci < p.Cin_real) {
+                float* dst = p.dw + ci * p.s_ci + tap * p.s_tap;
+#pragma unroll 1
+                for (int j = 0; j < 16; ++j) {
+                    const int co = cob + 2 * j;
+                    const float v = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+                    if (co < p.Cout && v != 0.f) atomicAdd(dst + co * p.s_co, v);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// reduction of the row kernel's partial tiles: dw[co][ci][iy*KW + t] += sum over slices
+struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, BNc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; int overwrite; };
+// sum over the slices of four consecutive partial-tile elements (16-byte loads, four slices requested before the first addition;
+// slice order kept): the reduce kernels stream the whole workspace once and were running at 2.5 TB/s with scalar loads
+__device__ __forceinline__ f32x4 slice_sum4(const float* ws, int nslice, size_t stride, size_t off) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= nslice; z += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(ws + (size_t)(z + j) * stride + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a += v[j];
+    }
+    for (; z < nslice; ++z) a += *reinterpret_cast<const f32x4*>(ws + (size_t)z * stride + off);
+    return a;
+}
+
+__global__ void wgrad_row_reduce_kernel(WgRowRedK p) {
+    const int tile_elems = p.KW * p.BMc * p.BNc;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // 4 consecutive in-channels per thread
+    if (i >= (long long)p.gx * tile_elems) return;
+    const int bx = (int)(i / tile_elems), e = (int)(i - (long long)bx * tile_elems);
+    const int t = e / (p.BMc * p.BNc), e2 = e - t * (p.BMc * p.BNc);
+    const int r = e2 / p.BNc, c = e2 - r * p.BNc;
+    const int tiles = p.tiles_co * p.tiles_ci;
+    const int iy = bx / tiles, rem = bx - iy * tiles;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co = tco * p.BMc + r, ci = tci * p.BNc + c;
+    if (co >= p.Cout || ci >= p.Cin_real) return;
+    const f32x4 a = slice_sum4(p.ws, p.nslice, (size_t)p.gx * tile_elems, (size_t)bx * tile_elems + e);
+    float* d = p.dw + co * p.s_co + ci * p.s_ci + (iy * p.KW + t) * p.s_tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ci + j < p.Cin_real) d[j * p.s_ci] = p.overwrite ? a[j] : d[j * p.s_ci] + a[j];
+}
+
+// bias gradient of the row kernel's workspace path: dbias[co] += sum over (slice, filter row of the centre time slab, ci tile) of the
+// partial column sums, in a fixed order (block = 32 channels x 8 partial lanes)
+struct WgBiasRedK { const float* wsb; float* dbias; int nslice, gx, tiles_co, tiles_ci, KW, kt, BMc, Cout; };
+__global__ __launch_bounds__(1024) void wgrad_row_bias_reduce_kernel(WgBiasRedK p) {
+    // block = 32 channels x 32 partial lanes; a lane walks its items eight loads at a time (a few thousand partials per channel on
+    // the large shapes: as a serial chain on 8 lanes this kernel took ~250 us)
+    __shared__ float red[32][33];
+    const int gpt = p.BMc / 32;
+    const int tco = blockIdx.x / gpt, cg = blockIdx.x - tco * gpt;
+    const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
+    const int tiles = p.tiles_co * p.tiles_ci, per = p.KW * p.tiles_ci, nitem = p.nslice * per;
+    const int irow0 = (p.kt >> 1) * p.KW;
+    auto item = [&](int i) __attribute__((always_inline)) -> float {
+        if (i >= nitem) return 0.f;
+        const int bz = i / per, r = i - bz * per;
+        const int iy = r / p.tiles_ci, tci = r - iy * p.tiles_ci;
+        const int bx = (irow0 + iy) * tiles + tco * p.tiles_ci + tci;
+        return p.wsb[((size_t)bz * p.gx + bx) * p.BMc + cg * 32 + c];
+    };
+    float a = 0.f;
+    for (int i = l; i < nitem; i += 32 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = item(i + 32 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    red[l][c] = a;
+    __syncthreads();
+    if (l == 0) {
+        for (int j = 1; j < 32; ++j) a += red[j][c];
+        const int co = tco * p.BMc + cg * 32 + c;
+        if (co < p.Cout) p.dbias[co] += a;
+    }
+}
+
+// Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
+struct WgRedK { const float* ws; float* dw; int nslice, gx, gx_per_tap, tiles_ci, BMc, BNc, Cout, Cin_real; long long s_co, s_ci, s_tap; int overwrite; };
+__global__ void wgrad_reduce_kernel(WgRedK p) {
+    const int tile_elems = p.BMc * p.BNc;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (long long)p.gx * tile_elems) return;
+    const int bx = (int)(i / tile_elems), e = (int)(i - (long long)bx * tile_elems);
+    const int r = e / p.BNc, c = e - r * p.BNc;
+    // decode bx exactly like the kernel: tap = bx / (tiles_co*tiles_ci), rem -> (tco, tci)
+    const int per_tap = p.gx_per_tap;
+    const int tap = bx / per_tap, rem = bx - tap * per_tap;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co = tco * p.BMc + r, ci = tci * p.BNc + c;
+    if (co >= p.Cout || ci >= p.Cin_real) return;
+    const f32x4 a = slice_sum4(p.ws, p.nslice, (size_t)p.gx * tile_elems, (size_t)bx * tile_elems + e);
+    float* d = p.dw + co * p.s_co + ci * p.s_ci + tap * p.s_tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ci + j < p.Cin_real) d[j * p.s_ci] = p.overwrite ? a[j] : d[j * p.s_ci] + a[j];
+}
+
+}  // namespace
+
+// Validates a weight-gradient request and derives tile shape, grid and row split.
+// mode: 0 = one tap per workgroup (conv_wgrad_kernel), 1 = one filter row per workgroup (conv_wgrad_row_kernel; ta = WM)
+static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit, int& mode) {
+    if (!d || !d->x || !d->dy || !d->dw) return DVD_E_ARG;
+    int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
+    const bool pow2 = logH >= 0 && logW >= 0;
+    if (!pow2) logH = logW = -1;           // division-based indexing, one-tap kernel only
+    if (d->up2 && ((d->H | d->W) & 1)) return DVD_E_SHAPE;
+    if ((d->C & 7) || (d->ldx & 7) || (d->Cy & 7) || (d->ldy & 7) || !(d->kt & d->kh & d->kw & 1)) return DVD_E_SHAPE;
+    if (d->Cout > d->Cy || d->Cin_real > d->C) return DVD_E_ARG;
+    if (d->dtype != DVD_BF16 && d->dtype != DVD_F32) return DVD_E_ARG;
+    const long long M = (long long)d->frames * d->T * d->H * d->W;
+    if (M >= (1ll << 31) - 64) return DVD_E_SHAPE;
+    p.x = (const char*)d->x; p.dy = (const char*)d->dy; p.dw = d->dw;
+    p.M = (int)M; p.C = d->C; p.ldx = d->ldx; p.Cin_real = d->Cin_real; p.Cout = d->Cout; p.Cy = d->Cy; p.ldy = d->ldy;
+    p.T = d->T; p.H = d->H; p.W = d->W; p.logH = logH; p.logW = logW;
+    p.Hin = d->up2 ? d->H / 2 : d->H; p.Win = d->up2 ? d->W / 2 : d->W;
+    p.kt = d->kt; p.kh = d->kh; p.kw = d->kw; p.up2 = d->up2; p.relu_in = d->relu_in;
+    // bf16: 256-wide tile along whichever channel axis is long enough (2x the MFMAs per barrier)
+    ta = 2; tb = 2;
+    if (d->dtype == DVD_BF16) {
+        if (d->Cout >= 192) ta = 4;
+        else if (d->Cin_real >= 192) tb = 4;
+    }
+    static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
+    mode = (use_row && pow2 && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) &&
+            ((d->W >= 8 && (d->H * d->W) % 32 == 0) ||
+             // 4 x 4 frames (round 4): a 32-pixel step = two whole frames
+             (d->W == 4 && d->H == 4 && d->kt == 1 && d->T == 1 && !d->up2 && (d->frames & 1) == 0))) ? 1 : 0;
+    if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
+        const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
+        static const int force_wm = getenv("DVD_WGR_WM") ? atoi(getenv("DVD_WGR_WM")) : 0;
+        ta = d->Cout <= 64 ? 1 : (w4 <= w2 ? 4 : 2); tb = 1;
+        if (force_wm && ta > force_wm) ta = force_wm;
+        // 128-channel output tile, 5 taps: take 128 input channels too (one 8-wave workgroup per CU whose halves stagger their
+        // loads, like the 256-channel tile) when that pads Cin no further: 1.20 -> 1.33 PF/s on 3.1 M x 256 -> 384; with 3 taps
+        // the two 4-wave workgroups per CU of the 64-channel form stay 3 % ahead
+        static const int wide = getenv("DVD_WGR_NH4") ? atoi(getenv("DVD_WGR_NH4")) : 1;
+        if (wide && ta == 2 && d->kw == 5 && !d->up2 && (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64) tb = 2;
+    }
+    p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
+    p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
+    { static const int xr = getenv("DVD_WG_XCD") ? atoi(getenv("DVD_WG_XCD")) : 1; p.xcd_remap = xr; }
+    {
+        const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
+        const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;
+        p.x_bytes = ((rows_in - 1) * (size_t)d->ldx + d->C) * esz;
+        p.dy_bytes = (((size_t)M - 1) * (size_t)d->ldy + d->Cy) * esz;
+        p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
+    }
+    const int ntaps = d->kt * d->kh * d->kw;
+    msplit = d->msplit;
+    if (msplit < 1) {   // auto: ~16 workgroups per CU, every workgroup keeping >= 4k rows of reduction.  Swept on the
+                        // full step with the workspace reduction (ms of wgrad per step): (1024,8192) 292,
+                        // (1536,8192) 267, (3072,4096) 247, (4096,4096) 243, (6144,4096) 242, (8192,2048) 252
+        static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 2048;   // re-swept with whole-round grids: 4096 185.6, 2048 183.2, 1024 183.5 ms
+        static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 4096;
+        // (rounds 1-3, swept with whole-round grids: 1024 187.7, 1536 185.1, 2048 190.8, 3072 192.2 ms of weight gradients.  End of round 4 -- the
+        //  chain's kernels no longer leave the side stream the CUs they used to -- fewer, longer slices win on the STEP: 256 503.4 / 503.8,
+        //  384 498.1 / 498.1, 512 495.6 / 495.7, 768 497.7 / 498.5, 1024 498.4 / 497.3, 1536 500.4 / 500.3, 3072 501.3 ms, one box)
+        static const long long tgt_row = getenv("DVD_WGR_TGT") ? atoll(getenv("DVD_WGR_TGT")) : 512;
+        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps);
+        msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
+        const long long cap = M / minrows > 0 ? M / minrows : 1;
+        if (msplit > cap) msplit = cap;
+        // whole rounds: the workgroups run `conc` at a time (register / LDS limited); a grid a few workgroups over a
+        // multiple of that pays a full extra round (20 x 103 = 2060 workgroups = 8.05 rounds of 256 -> 9 rounds)
+        static const int quant = getenv("DVD_WG_QUANT") ? atoi(getenv("DVD_WG_QUANT")) : 1;
+        const long long conc = 256ll * ((mode == 1 && (ta == 4 || tb == 2)) ? 1 : 2);
+        if (quant && base * msplit > conc) {
+            const long long rounds = (base * msplit + conc / 2) / conc;           // nearest
+            long long ms2 = rounds * conc / base;
+            if (ms2 >= 1 && ms2 <= cap) msplit = ms2;
+        }
+    }
+    long long rows = (M + msplit - 1) / msplit;
+    {   // a workgroup's row slice is addressed with 32-bit byte offsets
+        const long long ldmax = (d->ldx > d->ldy ? d->ldx : d->ldy) * (d->dtype == DVD_BF16 ? 2ll : 4ll);
+        const long long cap = (1ll << 31) / ldmax;
+        if (rows > cap) rows = cap;
+    }
+    rows = (rows + 31) / 32 * 32;
+    if (rows < 32) rows = 32;
+    msplit = (M + rows - 1) / rows;
+    p.rows_per_split = (int)rows;
+    grid = dim3(p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps), 1, (unsigned)msplit);
+    return DVD_OK;
+}
+
+extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
+    WgK p; dim3 grid; int ta, tb, mode; long long msplit;
+    if (const long long thin = dvd_wgrad_thin_ws_floats(d)) return thin;       // 3 (8) channels on one side: wgrad_thin.hip
+    if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
+    if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) + msplit * (long long)grid.x * (ta * 64);   // + bias partials
+    return msplit * (long long)grid.x * (ta * 64) * (tb * 64);
+}
+
+extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
+    WgK p; dim3 grid; int ta, tb, mode; long long msplit;
+    const int rc = wgrad_plan(d, p, grid, ta, tb, msplit, mode);
+    if (rc != DVD_OK) return rc;
+    const int ntaps = d->kt * d->kh * d->kw;
+    if (d->ws && dvd_wgrad_thin_ws_floats(d)) {    // the thin ends of the networks (stems, RGB layer): taps folded into the matrix dimension
+        if (d->overwrite && (d->s_tap != 1 || d->s_ci != ntaps || d->s_co != (long long)d->Cin_real * ntaps)) return DVD_E_ARG;
+        ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, 0, d->relu_in << 1);
+        prof.r.variant = 3;
+        return dvd_wgrad_thin(d, stream);
+    }
+    if (d->ws && msplit > 1) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw
+    const int overwrite = d->overwrite != 0;       // dw = result instead of dw += result (the caller need not zero it)
+    if (overwrite) {
+        if (d->s_tap != 1 || d->s_ci != ntaps || d->s_co != (long long)d->Cin_real * ntaps) return DVD_E_ARG;   // dense [co][ci][tap] only
+        if (!p.ws && hipMemsetAsync(d->dw, 0, (size_t)d->Cout * d->Cin_real * ntaps * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return DVD_E_LAUNCH;                   // single slice: the kernel adds with atomics
+    }
+    p.wsb = (p.ws && mode == 1) ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) : nullptr;
+    ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
+                   d->up2 | (d->relu_in << 1));
+    hipStream_t st = (hipStream_t)stream;
+    prof.r.variant = mode == 1 ? 1 : 2;
+    if (mode == 1) {
+#define LAUNCH_ROW(WM_, KW_)                                                                        \
+        do { if (d->relu_in) conv_wgrad_row_kernel<WM_, KW_, true><<<grid, WM_ * 128, 0, st>>>(p);      \
+             else conv_wgrad_row_kernel<WM_, KW_, false><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
+#define LAUNCH_ROW_UP(WM_)                                                                          \
+        do { if (d->relu_in) conv_wgrad_row_kernel<WM_, 3, true, true><<<grid, WM_ * 128, 0, st>>>(p);  \
+             else conv_wgrad_row_kernel<WM_, 3, false, true><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
+#define LAUNCH_ROW_W(KW_)                                                                           \
+        do { if (d->relu_in) conv_wgrad_row_kernel<2, KW_, true, false, 4><<<grid, 512, 0, st>>>(p);    \
+             else conv_wgrad_row_kernel<2, KW_, false, false, 4><<<grid, 512, 0, st>>>(p); } while (0)
+        if (d->up2) { if (ta == 4) LAUNCH_ROW_UP(4); else if (ta == 2) LAUNCH_ROW_UP(2); else LAUNCH_ROW_UP(1); }
+        else if (tb == 2) { if (d->kw == 5) LAUNCH_ROW_W(5); else LAUNCH_ROW_W(3); }
+        else
+        if (ta == 4)      { if (d->kw == 5) LAUNCH_ROW(4, 5); else LAUNCH_ROW(4, 3); }
+        else if (ta == 2) { if (d->kw == 5) LAUNCH_ROW(2, 5); else LAUNCH_ROW(2, 3); }
+        else              { if (d->kw == 5) LAUNCH_ROW(1, 5); else LAUNCH_ROW(1, 3); }
+#undef LAUNCH_ROW
+#undef LAUNCH_ROW_UP
+#undef LAUNCH_ROW_W
+        if (p.ws) {
+            WgRowRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, ta * 64, tb * 64, d->kw, p.Cout, p.Cin_real,
+                        p.s_co, p.s_ci, p.s_tap, overwrite};
+            const long long n = (long long)grid.x * r.KW * r.BMc * r.BNc;
+            wgrad_row_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
+            if (p.dbias) {
+                WgBiasRedK b{p.wsb, p.dbias, (int)msplit, (int)grid.x, p.tiles_co, p.tiles_ci, d->kw, d->kt, ta * 64, p.Cout};
+                wgrad_row_bias_reduce_kernel<<<p.tiles_co * (ta * 64 / 32), 1024, 0, st>>>(b);
+            }
+        }
+        return launch_status();
+    }
+    if (d->dtype == DVD_BF16) {
+        if (ta == 4) conv_wgrad_kernel<bf16_t, 4, 2><<<grid, NT, 0, st>>>(p);
+        else if (tb == 4) conv_wgrad_kernel<bf16_t, 2, 4><<<grid, NT, 0, st>>>(p);
+        else conv_wgrad_kernel<bf16_t, 2, 2><<<grid, NT, 0, st>>>(p);
+    } else conv_wgrad_kernel<float, 2, 2><<<grid, NT, 0, st>>>(p);
+    if (p.ws) {
+        WgRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_co * p.tiles_ci, p.tiles_ci, ta * 64, tb * 64, p.Cout,
+                 p.Cin_real, p.s_co, p.s_ci, p.s_tap, overwrite};
+        const long long n = (long long)grid.x * r.BMc * r.BNc;
+        wgrad_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
+    }
+    return launch_status();
+}

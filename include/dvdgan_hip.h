@@ -36,6 +36,18 @@ extern "C" {
 #define DVD_ACT_SIGMOID 3
 
 int dvd_abi_version(void);              /* bumps when a signature changes                      */
+/* Layout handshake: sizeof() of descriptor struct `which` AS THIS LIBRARY WAS COMPILED (0 = dvd_conv_desc, 1 = dvd_wgrad_desc,
+ * 2 = dvd_gru_desc, 3 = dvd_sn_item, 4 = dvd_gru_stack_desc; -1 = unknown index).  A binding compares it with the size of its own
+ * mirror of the struct at load time (dvd_gan_amd/lib.py does; tests/test_abi_cpu.py also checks the stub printed in
+ * INTEGRATION.md): a descriptor that grew on one side only is caught before the library reads past the caller's struct.
+ * The reference boundary these structs stand in for is the nn.Module constructor / forward argument lists
+ * (Module/Generator.py:15, Module/Discriminators.py:219,371). */
+#define DVD_STRUCT_CONV 0
+#define DVD_STRUCT_WGRAD 1
+#define DVD_STRUCT_GRU 2
+#define DVD_STRUCT_SN_ITEM 3
+#define DVD_STRUCT_GRU_STACK 4
+int dvd_struct_size(int which);
 /* Optional measurement aid for bench.py: bracket every conv launch with HIP events on its stream.
  * kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Report drains the records,
  * returns the launch count, total milliseconds and total algorithmic FLOPs (2*M*Cout*C*taps). */
