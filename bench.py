@@ -233,10 +233,12 @@ def main():
                       3: hk + "<%s, 256x64 tile>" % a.dtype, 4: "conv_igemm_kernel<%s, 128x128 tile>" % a.dtype,
                       5: "conv_igemm_kernel<%s, 256x128 tile>" % a.dtype, 6: "conv_igemm_kernel<bf16, 256x256 tile, 8 waves>",
                       7: "conv_halo_gbs_kernel<bf16, 256x128 tile, 8x8 frames>",
-                      8: "conv_halo_gbs_kernel<bf16, 128x128 tile, 4x4 / 8x8 frames>", 9: "conv_thin_in_kernel<bf16, 3 -> 64 channels>"},
+                      8: "conv_halo_gbs_kernel<bf16, 128x128 tile, 4x4 / 8x8 frames>", 9: "conv_thin_in_kernel<bf16, 3 -> 64 channels>",
+                      10: "conv_group_gb_kernel<bf16, 256x128 tiles, grouped ConvGRU wavefront launches>",
+                      11: "conv_group_gbs_kernel<bf16, grouped ConvGRU wavefront launches on 4x4 / 8x8 frames>"},
                   1: {1: "conv_wgrad_row_kernel", 2: "conv_wgrad_kernel", 3: "wgrad_thin_kernel"}}
         for kind, name in ((0, "conv_igemm"), (1, "conv_wgrad")):
-            NV = 10
+            NV = 12
             nn, tms, fl = (C.c_longlong * NV)(), (C.c_double * NV)(), (C.c_double * NV)()
             lib.dvd_prof_report_variants(kind, NV, nn, tms, fl)          # totals of the instrumented step, per kernel variant
             mk = lambda v: {"launches": int(nn[v]), "ms": tms[v],
@@ -251,7 +253,7 @@ def main():
         F = F_GFLOP_PER_CLIP.get((a.ch, a.frames, a.size))
         dom = res["conv_igemm"]
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        roof = {"bound": "mfma", "kernel": "conv_halo_gb_kernel + conv_halo_gbs_kernel + conv_igemm_kernel <bf16> (forward + backward-data convolutions)" if a.dtype == "bf16" else "conv_halo_kernel + conv_igemm_kernel <f32>",
+        roof = {"bound": "mfma", "kernel": "conv_halo_gb_kernel + conv_group_gb_kernel + conv_halo_gbs_kernel + conv_group_gbs_kernel + conv_igemm_kernel <bf16> (forward + backward-data convolutions)" if a.dtype == "bf16" else "conv_halo_kernel + conv_igemm_kernel <f32>",
                 "achieved": round(dom["tflops"], 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(dom["tflops"] / peak, 4), "traffic": hbm_traffic(a, batch),
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),

@@ -111,6 +111,9 @@ struct GruEpi {
     float* slabs; unsigned* tickets;
 };
 extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream);
+// Internal: n independent convolutions (d[i], gate epilogue g[i], mode 0 = none / 6 = direct epilogue behind the in-launch split-K
+// combine) in ONE launch of kernel `kind`; see conv_igemm.hip
+extern "C" int dvd_conv_forward_group(const dvd_conv_desc* d, const GruEpi* g, int n, int kind, int run, void* stream);
 // Internal: weight gradients with 3 (8) channels on one side and 64 on the other (wgrad_thin.hip); 0 floats = not served there
 long long dvd_wgrad_thin_ws_floats(const dvd_wgrad_desc* d);
 int dvd_wgrad_thin(const dvd_wgrad_desc* d, void* stream);

@@ -146,15 +146,15 @@ __device__ __forceinline__ void epi_run(Stage stage, Load load, Compute compute)
 //                           order, reset the ticket for the next launch on the stream, go on into the gate epilogue.
 // The sum is the same whichever workgroup arrives last: ns == 2 adds the other slab onto the registers (a + b == b + a), ns > 2
 // re-reads all ns slabs, its own included, into zeroed accumulators in slice order.  Slab layout (private to this function):
-// [tile = blockIdx.x][slice][wave][tm][tn][quad][lane] x 16 bytes.  cdna_hip_programming.md section 5 (split-K reduction recipe).
+// [tile][slice][wave][tm][tn][quad][lane] x 16 bytes.  cdna_hip_programming.md section 5 (split-K reduction recipe).
 template <int TM>
-__device__ __forceinline__ bool splitk_combine(const ConvK& p, f32x16 (&acc)[TM][2], float* lds0, int lane, int z) {
+__device__ __forceinline__ bool splitk_combine(const ConvK& p, f32x16 (&acc)[TM][2], float* lds0, int lane, int z, int ltile) {
     constexpr unsigned kWaveBytes = TM * 2 * 4 * 1024;
     constexpr int kSc1 = 16;                          // cache-policy bit 4 on gfx950: sc1
     const int ns = p.nsplit;
     const int wave = threadIdx.x >> 6;
     const unsigned tileBytes = (blockDim.x >> 6) * kWaveBytes;
-    const size_t tile = blockIdx.x;
+    const size_t tile = (size_t)ltile;          // index of this output tile among the convolution's tiles (== blockIdx.x outside grouped launches)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((char*)p.g.slabs + tile * ns * (size_t)tileBytes), 0, (unsigned)ns * tileBytes, 0x00020000);
     const unsigned lo = wave * kWaveBytes + lane * 16;
@@ -222,7 +222,7 @@ __device__ __forceinline__ bool splitk_combine(const ConvK& p, f32x16 (&acc)[TM]
 // DEEP: deeper operand pipelines for the gate epilogues (kernels whose accumulators live in the unified register file can spend the
 // registers of already-staged sub-tiles on operands in flight)
 template <typename T, int TM, int DEEP = 0, bool COMBINE = true, class RelRow>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][2], float* ep, int lane, int col, int z,
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][2], float* ep, int lane, int col, int z, int ltile,
                                               long long row0, RelRow relrow) {
     constexpr unsigned esz = sizeof(T);
     constexpr int R = 4 * TM;
@@ -256,7 +256,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
 #endif
     // split-K with a gate epilogue: only the last slice workgroup of the tile to arrive goes on, holding the full sums
     if constexpr (COMBINE)
-        if (mode != 0 && p.nsplit > 1 && !splitk_combine<TM>(p, acc, ep - (threadIdx.x >> 6) * (32 * 64), lane, z)) return;
+        if (mode != 0 && p.nsplit > 1 && !splitk_combine<TM>(p, acc, ep - (threadIdx.x >> 6) * (32 * 64), lane, z, ltile)) return;
     if (mode == 1) {              // [u|r] = sigmoid(acc + gx);  hr = h_prev * r        (ConvGRU.py:47-49)
         constexpr int D = kB ? 3 : 1;
         const int h = p.g.h;
@@ -499,9 +499,25 @@ template <bool UP2> struct HaloGeo {
     static __device__ __forceinline__ int sw(int hy, int hx) { return ((hx >> 2) + SWA * hy) & 3; }
 };
 
+// Several independent convolutions served by ONE grid (conv_gb.hip: group_dispatch).  Workgroup b runs on XCD b % 8 as that XCD's
+// (b / 8)-th workgroup, and an XCD hands its i-th workgroup to CU i % 32 (tools/place_probe.hip): every XCD takes a contiguous
+// eighth of each member's workgroups (tiles x K slices) and walks them in the order
+//     `head` of order[0] | `head` of order[1] | rest of order[0] | rest of order[1] | order[2] | ...
+// with the members sorted by decreasing K length: the two workgroups that share a CU in the first round belong to different
+// members, so they reach their epilogues at different times, and the short tiles fill the tail.  Passed by value (kernel arguments).
+constexpr int kGroupMax = 6;
+struct ConvGroup {
+    int n, head, nslots;
+    int order[kGroupMax];                   // members by decreasing K length
+    int wgs[kGroupMax];                     // workgroups of member g
+    ConvK c[kGroupMax];
+};
+static_assert(sizeof(ConvGroup) <= 3584, "ConvGroup must fit the kernel argument segment");
+
 // conv_gb.hip (weights from L2, fragment-major): launchers for conv_igemm.hip's dispatch
 void launch_gb(const ConvK& p, int variant, bool relu_in, bool up2, dim3 grid, hipStream_t st);
 void launch_gbs(const ConvK& p, int S, bool big, bool relu_in, dim3 grid, hipStream_t st);
+void launch_group(const ConvGroup& grp, int kind, hipStream_t st);
 
 }  // namespace dvdk
 using namespace dvdk;

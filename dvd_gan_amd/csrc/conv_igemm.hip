@@ -265,14 +265,14 @@ __global__ __launch_bounds__(128 * WN) void conv_igemm_kernel(ConvK p) {
     float* ep = reinterpret_cast<float*>(&smem[0][0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     if (p.pm) {          // rows of the tile are scattered over the tensor: offsets from its start (small tensors only, see conv_plan)
-        conv_epilogue<T, TM, 0, WN == 2>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, 0ll, [&](int tm, int j) __attribute__((always_inline)) {
+        conv_epilogue<T, TM, 0, WN == 2>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (int)blockIdx.x, 0ll, [&](int tm, int j) __attribute__((always_inline)) {
             const int mp = m0 + wm * (TM * 32) + tm * 32 + j * 8 + erow;
             return mp < p.M ? memrow(mp) : -1;
         });
         return;
     }
     // (WN == 2: the 8-wave tile has no registers to spare for the in-launch split-K combine)
-    conv_epilogue<T, TM, 0, WN == 2>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (long long)m0, [&](int tm, int j) __attribute__((always_inline)) {
+    conv_epilogue<T, TM, 0, WN == 2>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (int)blockIdx.x, (long long)m0, [&](int tm, int j) __attribute__((always_inline)) {
         const int rr = wm * (TM * 32) + tm * 32 + j * 8 + erow;
         return m0 + rr < p.M ? rr : -1;
     });
@@ -540,7 +540,7 @@ __device__ __forceinline__ void conv_halo_tile(const ConvK& p, char* const smem,
     float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 64);
     const int ecol = (lane & 7) * 8, erow = lane >> 3;
     const long long frame_row0 = (long long)ft * (p.H * p.W);
-    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, frame_row0, [&](int tm, int j) __attribute__((always_inline)) {
+    conv_epilogue<T, TM>(p, acc, ep, lane, n0 + wn * 64 + ecol, z, (int)blockIdx.x, frame_row0, [&](int tm, int j) __attribute__((always_inline)) {
         const int pi = wm * (TM * 32) + tm * 32 + j * 8 + erow;          // pixel of the patch, row-major 16 wide
         return (y0 + (pi >> 4)) * p.W + x0 + (pi & 15);
     });
@@ -806,6 +806,61 @@ extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, voi
     else if (d->dtype == DVD_F32) LAUNCH_CONV(float);
     else return DVD_E_ARG;
 #undef LAUNCH_CONV
+    return launch_status();
+}
+
+// Several INDEPENDENT convolutions in one launch (conv_gb.hip: group_dispatch; gru.hip: the layer wavefront of a ConvGRU stack).
+// Every member: bf16, fragment-major weights supplied (d[i].wq), square 3 x 3 / 5 x 5 taps, no input ReLU / upsample, all served by
+// the ONE kernel `kind` names (0 / 1 = conv_halo_gb 256 x 128 / 128 x 128 tiles: frames >= 16 pixels; 2 / 3 = whole 8 x 8 frames,
+// 256- / 128-row tiles; 4 = whole 4 x 4 frames).  g[i].mode: 0 = direct epilogue, 1-5 = ConvGRU gate epilogues, 6 = direct epilogue
+// behind an in-launch split-K combine; nsplit > 1 needs mode != 0 (g[i].slabs; g[i].tickets = the stream's ticket buffer: member i
+// takes counters [i * 1024, (i + 1) * 1024)).  run: ConvGroup::head, workgroups of the two longest members an XCD starts with (<= 0: 32).
+extern "C" int dvd_conv_forward_group(const dvd_conv_desc* d, const GruEpi* g, int n, int kind, int run, void* stream) {
+    if (!d || !g || n < 1 || n > kGroupMax || kind < 0 || kind > 4) return DVD_E_ARG;
+    ConvGroup grp = {};
+    grp.n = n;
+    double flops = 0; long long Msum = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvPlan pl;
+        const GruEpi* gi = g[i].mode ? &g[i] : nullptr;
+        const int rc = conv_plan(&d[i], gi, grp.c[i], pl);
+        if (rc != DVD_OK) return rc;
+        ConvK& p = grp.c[i];
+        if (d[i].dtype != DVD_BF16 || !p.wq || d[i].wq_kind > 1 || d[i].relu_in || d[i].up2 || d[i].ws) return DVD_E_ARG;
+        long long mtiles;
+        if (kind <= 1) {
+            if (!pl.halo || d[i].H < (kind == 0 ? 16 : 8)) return DVD_E_SHAPE;
+            mtiles = cdiv(pl.M, kind == 0 ? 256 : 128);
+        } else {
+            const int S = kind == 4 ? 4 : 8;
+            if (!pl.smallf || d[i].W != S) return DVD_E_SHAPE;
+            mtiles = cdiv(d[i].frames, kind == 2 ? 4 : kind == 3 ? 2 : 8);
+        }
+        p.tilesN = (d[i].Cout + BN - 1) / BN;
+        const long long tiles = mtiles * p.tilesN;
+        if (p.nsplit > 1) {
+            if (!gi || tiles > 1024) return DVD_E_SHAPE;
+            p.g.tickets += i * 1024;
+        }
+        if (tiles * p.nsplit > (1 << 20)) return DVD_E_SHAPE;
+        grp.wgs[i] = (int)(tiles * p.nsplit);
+        flops += 2.0 * (double)pl.M * d[i].Cout * d[i].C * d[i].kh * d[i].kw;
+        Msum += pl.M;
+    }
+    // slot order (ConvGroup): members by decreasing K length of a workgroup
+    {
+        long long len[kGroupMax];
+        for (int i = 0; i < n; ++i) { grp.order[i] = i; len[i] = (long long)grp.c[i].kchunks * d[i].kh * d[i].kw / grp.c[i].nsplit; }
+        for (int i = 1; i < n; ++i)
+            for (int j = i; j > 0 && len[grp.order[j]] > len[grp.order[j - 1]]; --j) { const int t = grp.order[j]; grp.order[j] = grp.order[j - 1]; grp.order[j - 1] = t; }
+        long long slots = 0;
+        for (int i = 0; i < n; ++i) slots += (grp.wgs[i] + 7) / 8;
+        grp.nslots = (int)(8 * slots);
+        grp.head = run > 0 ? run : run < 0 ? 0 : 32;
+    }
+    ProfScope prof(0, flops, stream, Msum, d[0].C, d[0].Cout, d[0].kh * d[0].kw, n, 0);
+    prof.r.variant = kind <= 1 ? 10 : 11;
+    launch_group(grp, kind, (hipStream_t)stream);
     return launch_status();
 }
 

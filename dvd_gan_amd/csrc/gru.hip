@@ -285,6 +285,11 @@ extern "C" long long dvd_convgru_ws_floats(int dtype, int B, int H, int W, int h
     return n;
 }
 
+static int capped_nsplit(const dvd_gru_desc* d, long long M, int Cout, int C, int ntaps) {
+    const int ns = dvd_conv_pick_nsplit(d->dtype, M, Cout, C, ntaps);
+    return (d->ns_cap > 0 && ns > d->ns_cap) ? d->ns_cap : ns;
+}
+
 extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
     if (!d || !d->gx || !d->w_ur || !d->w_o || !d->h_all || !d->u_all || !d->hr_all || !d->ws) return DVD_E_ARG;
     if (!d->infer && (!d->r_all || !d->o_all)) return DVD_E_ARG;
@@ -296,8 +301,8 @@ extern "C" int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream) {
     const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
     const size_t step = (size_t)M * h * esz;
     const size_t astep = d->infer ? 0 : step;       // inference: u / h*r are one-step scratch, r and o are not stored at all
-    const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, 2 * h, h, ntaps);
-    const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);
+    const int ns_ur = capped_nsplit(d, M, 2 * h, h, ntaps);
+    const int ns_o = capped_nsplit(d, M, h, h, ntaps);
     const int nmax = !d->tickets ? 1 : d->combine_max > 0 ? d->combine_max : inlaunch_max();    // convs with up to nmax slices apply the gates in their epilogue
     const unsigned grid = cdiv(M * (h / 8), 256);
     for (int t = 0; t < d->T; ++t) {
@@ -354,8 +359,8 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
     if (M * (d->hidden / 8) >= (1ll << 31)) return DVD_E_SHAPE;
     const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
     const size_t step = (size_t)M * h * esz;
-    const int ns_o = dvd_conv_pick_nsplit(d->dtype, M, h, h, ntaps);        // d(hr)  = convT(d pre_o)
-    const int ns_ur = dvd_conv_pick_nsplit(d->dtype, M, h, 2 * h, ntaps);   // dh    += convT(d pre_u | d pre_r)
+    const int ns_o = capped_nsplit(d, M, h, h, ntaps);        // d(hr)  = convT(d pre_o)
+    const int ns_ur = capped_nsplit(d, M, h, 2 * h, ntaps);   // dh    += convT(d pre_u | d pre_r)
     const int nmax = !d->tickets ? 1 : d->combine_max > 0 ? d->combine_max : inlaunch_max();
     const unsigned grid = cdiv(M * (h / 8), 256);
     hipError_t e = hipMemsetAsync(d->carry, 0, (size_t)M * h * sizeof(float), S_);
@@ -417,4 +422,297 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
     }
     if (d->dh0) gru_dh0_kernel<<<cdiv(M * h, 256), 256, 0, S_>>>(d->carry, d->ws, ns_pending, d->dh0, M, h);
     return launch_status();
+}
+
+// ============================================================================ layer wavefront over a ConvGRU stack (round 5)
+// See include/dvdgan_hip.h (dvd_gru_stack_desc).  Launch pair k of the forward pass:
+//   U group:  [u|r] convolution of (layer l, step t = k - 2 l) for every layer with 0 <= t < T
+//   O group:  out-gate convolution of the same (l, t), plus the x-part convolution of (layer l >= 1, step k - 2 l + 1) -- its input,
+//             layer l-1's state of that step, was finished by the O group of pair k - 1; its result is read by the U group of pair k + 1
+// and of the backward pass (layers in reverse, layer l works on step t = T - 1 - (k - 2 (L - 1 - l))):
+//   A group:  d(h*r) convolution (epilogue: reset-gate step)
+//   B group:  d[u|r] convolution (epilogue: carry + first half of step t - 1), plus for l >= 1 the x-part backward-data convolution of
+//             step t (all three gate gradients of the step are complete), whose result is layer l-1's dh_out of step t -- needed by
+//             layer l-1's B convolution of step t + 1 in pair k + 1.
+// The steps without a previous state (t = 0, no h0) and the first BPTT step of a layer run the elementwise gate kernels.
+namespace {
+
+struct Member { dvd_conv_desc d; long long tiles; int kchunks; int gate; };
+constexpr int kMaxMember = 2 * DVD_GRU_STACK_MAX;
+
+// kernel family serving a stack: 0 = frames >= 16 pixels (256 x 128 tiles), 2 / 3 = 8 x 8 frames (256- / 128-row tiles), 4 = 4 x 4
+int stack_kind(const dvd_gru_stack_desc* s) {
+    const dvd_gru_desc& a = s->layer[0];
+    if (a.H != a.W || ilog2_exact(a.H) < 0) return -1;
+    if (a.H >= 16) return 0;
+    if (a.H == 4) return 4;
+    if (a.H != 8) return -1;
+    long long t256 = 0;                              // tiles of the U group on 256-row tiles
+    for (int l = 0; l < s->n_layers; ++l) t256 += (long long)cdiv(a.B, 4) * cdiv(2 * s->layer[l].hidden, 128);
+    static const int k8 = getenv("DVD_STACK_K8") ? atoi(getenv("DVD_STACK_K8")) : 0;
+    if (k8) return k8;
+    return t256 >= 256 ? 2 : 3;
+}
+long long kind_mtiles(int kind, int B, int H, int W) {
+    const long long M = (long long)B * H * W;
+    return kind == 0 ? cdiv(M, 256) : kind == 1 ? cdiv(M, 128) : cdiv(B, kind == 2 ? 4 : kind == 3 ? 2 : 8);
+}
+long long kind_tile_floats(int kind) { return (kind == 0 || kind == 2) ? 32768 : 16384; }     // accumulators of one output tile
+
+int stack_check(const dvd_gru_stack_desc* s, bool backward) {
+    if (!s || s->n_layers < 1 || s->n_layers > DVD_GRU_STACK_MAX) return DVD_E_ARG;
+    const dvd_gru_desc& a = s->layer[0];
+    if (a.dtype != DVD_BF16 || a.T <= 0 || a.B <= 0 || !a.tickets || !s->ws) return DVD_E_ARG;
+    if (stack_kind(s) < 0) return DVD_E_SHAPE;
+    for (int l = 0; l < s->n_layers; ++l) {
+        const dvd_gru_desc& d = s->layer[l];
+        if (d.dtype != a.dtype || d.T != a.T || d.B != a.B || d.H != a.H || d.W != a.W) return DVD_E_ARG;
+        if (d.hidden <= 0 || (d.hidden & 7) || (d.k != 3 && d.k != 5)) return DVD_E_SHAPE;
+        if ((long long)d.B * d.H * d.W * (d.hidden / 8) >= (1ll << 31)) return DVD_E_SHAPE;
+        if (!d.gx || !d.h_all || !d.u_all || !d.hr_all) return DVD_E_ARG;
+        if (l > 0 && (s->cin[l] != s->layer[l - 1].hidden || d.gx_stride != (long long)d.B * d.H * d.W * 3 * d.hidden)) return DVD_E_ARG;
+        if (!backward) {
+            if (!d.w_ur || !d.w_o || !d.w_ur_q || !d.w_o_q) return DVD_E_ARG;
+            if (!d.infer && (!d.r_all || !d.o_all)) return DVD_E_ARG;
+            if (l > 0 && (!s->wx[l] || !s->wx_q[l] || !s->bx[l])) return DVD_E_ARG;
+        } else {
+            if (!d.wd_ur || !d.wd_o || !d.wd_ur_q || !d.wd_o_q || !d.r_all || !d.o_all || !d.dg || !d.carry) return DVD_E_ARG;
+            if (l > 0 && (!s->wdx[l] || !s->wdx_q[l] || !s->dh_mid[l])) return DVD_E_ARG;
+        }
+    }
+    return DVD_OK;
+}
+
+void member_conv(Member& m, const dvd_gru_desc& L, const void* in, int C, int ldi, const void* w, const void* wq, int Cout, int kind) {
+    m = Member{};
+    dvd_conv_desc& d = m.d;
+    d.dtype = L.dtype; d.frames = L.B; d.T = 1; d.H = L.H; d.W = L.W; d.C = C; d.ldi = ldi; d.Cout = Cout; d.ldo = Cout;
+    d.kt = 1; d.kh = L.k; d.kw = L.k; d.nsplit = 1; d.in = in; d.w = w; d.wq = wq; d.wq_kind = 1;
+    m.tiles = kind_mtiles(kind, L.B, L.H, L.W) * cdiv(Cout, 128);
+    m.kchunks = (C + 31) / 32;
+}
+
+// Split-K factors of one grouped launch and the slab space behind them; launches unless `dry`.
+int run_group(const dvd_gru_stack_desc* s, int kind, Member* m, GruEpi* g, int n, void* stream, bool dry, long long& ws_need, bool backward) {
+    if (n == 0) return DVD_OK;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) total += m[i].tiles;
+    static const long long tgt_env = getenv("DVD_STACK_TGT") ? atoll(getenv("DVD_STACK_TGT")) : 0;       // (sweep aids)
+    static const long long cap_env = getenv("DVD_STACK_NSMAX") ? atoll(getenv("DVD_STACK_NSMAX")) : 0;
+    // measured (tools/gru_microbench.py stack, B = 64): (target, cap) = (768, 4) 5.46 / 6.99 ms forward / backward on 4 x 4 frames,
+    // (768, 8) 5.66 / 6.16; 8 x 8 frames: (768, 4) 14.86 / 15.09, (768, 8) 14.93 / 15.95, (384, 4) 14.46 / 16.53, (1536, *) slower
+    const long long cap = cap_env ? cap_env : (kind == 4 && backward) ? 8 : 4;
+    const long long target = tgt_env ? tgt_env : (kind == 0 || kind == 2) ? 512 : 768;
+    long long want = (target + total - 1) / total;
+    if (want > cap) want = cap;
+    long long cursor = 0;
+    dvd_conv_desc d[kMaxMember];
+    for (int i = 0; i < n; ++i) {
+        long long ns = want;
+        if (s->layer_policy)
+            ns = m[i].gate ? dvd_conv_pick_nsplit(DVD_BF16, (long long)m[i].d.frames * m[i].d.H * m[i].d.W, m[i].d.Cout, m[i].d.C,
+                                                  m[i].d.kh * m[i].d.kw) : 1;
+        if (s->layer[0].ns_cap > 0 && ns > s->layer[0].ns_cap) ns = s->layer[0].ns_cap;
+        if (ns > m[i].kchunks) ns = m[i].kchunks;
+        if (ns > 1 && m[i].tiles > 1024) ns = 1;
+        m[i].d.nsplit = (int)ns;
+        if (ns > 1) {
+            if (g[i].mode == 0) g[i].mode = 6;            // direct epilogue behind the in-launch combine
+            g[i].slabs = s->ws + cursor; g[i].tickets = s->layer[0].tickets;
+            cursor += ns * m[i].tiles * kind_tile_floats(kind);
+        }
+        d[i] = m[i].d;
+    }
+    if (cursor > ws_need) ws_need = cursor;
+    if (dry) return DVD_OK;
+    return dvd_conv_forward_group(d, g, n, kind, s->run, stream);
+}
+
+int stack_forward(const dvd_gru_stack_desc* s, void* stream, bool dry, long long& ws_need) {
+    const int L = s->n_layers, T = s->layer[0].T, kind = stack_kind(s);
+    const long long M = (long long)s->layer[0].B * s->layer[0].H * s->layer[0].W;
+    const size_t esz = 2;
+    for (int k = 0; k < T + 2 * (L - 1); ++k) {
+        Member mem[kMaxMember];
+        GruEpi epi[kMaxMember];
+        for (int phase = 0; phase < 2; ++phase) {                 // 0 = U group, 1 = O group
+            int n = 0;
+            for (int l = 0; l < L; ++l) {
+                const dvd_gru_desc& d = s->layer[l];
+                const int t = k - 2 * l, h = d.hidden;
+                if (t < 0 || t >= T) continue;
+                const size_t step = (size_t)M * h * esz, astep = d.infer ? 0 : step;
+                const char* hprev = t > 0 ? (const char*)d.h_all + (t - 1) * step : (const char*)d.h0;
+                const char* gx = (const char*)d.gx + (size_t)t * d.gx_stride * esz;
+                char* u = (char*)d.u_all + t * astep; char* r = d.infer ? nullptr : (char*)d.r_all + t * step;
+                char* o = d.infer ? nullptr : (char*)d.o_all + t * step; char* hr = (char*)d.hr_all + t * astep;
+                char* hn = (char*)d.h_all + t * step;
+                const float* h32p = (d.h32 && t > 0) ? d.h32 + (size_t)(t & 1) * M * h : nullptr;
+                float* h32n = d.h32 ? d.h32 + (size_t)((t + 1) & 1) * M * h : nullptr;
+                const unsigned grid = cdiv(M * (h / 8), 256);
+                const bool has_prev = dry || t > 0 || d.h0 != nullptr;      // (dry: workspace sizing, assume the larger schedule)
+                if (!has_prev) {                                  // step 0 without a supplied state: gates of the x-part alone
+                    if (dry) continue;
+                    using T_ = bf16_t;
+                    if (phase == 0)
+                        gru_gates_ur_kernel<T_><<<grid, 256, 0, S_>>>(nullptr, 0, (const T_*)gx, 3 * h, (const T_*)nullptr, (T_*)u, (T_*)r, (T_*)hr, M, h);
+                    else
+                        gru_out_kernel<T_><<<grid, 256, 0, S_>>>(nullptr, 0, (const T_*)gx, 3 * h, (const T_*)nullptr, h32p, (const T_*)u, (T_*)o,
+                                                                 (T_*)hn, h32n, M, h);
+                    continue;
+                }
+                GruEpi& g = epi[n];
+                g = GruEpi{};
+                g.h = h; g.ldg = 3 * h; g.gx = gx; g.hprev = hprev; g.h32p = h32p; g.u_in = u;
+                g.u = u; g.r = r; g.hr = hr; g.o = o; g.hn = hn; g.h32n = h32n;
+                if (phase == 0) {
+                    g.mode = 1;
+                    member_conv(mem[n], d, hprev, h, h, d.w_ur, d.w_ur_q, 2 * h, kind);
+                    mem[n].d.out = u;
+                } else {
+                    g.mode = 2;
+                    member_conv(mem[n], d, hr, h, h, d.w_o, d.w_o_q, h, kind);
+                    mem[n].d.out = hn;
+                }
+                mem[n].gate = 1;
+                ++n;
+            }
+            if (phase == 1)
+                for (int l = 1; l < L; ++l) {                     // x-part of layer l for step k - 2 l + 1
+                    const dvd_gru_desc& d = s->layer[l];
+                    const dvd_gru_desc& b = s->layer[l - 1];
+                    const int t = k - 2 * l + 1;
+                    if (t < 0 || t >= T) continue;
+                    epi[n] = GruEpi{};
+                    member_conv(mem[n], d, (const char*)b.h_all + (size_t)t * M * b.hidden * esz, b.hidden, b.hidden, s->wx[l], s->wx_q[l],
+                                3 * d.hidden, kind);
+                    mem[n].d.bias = s->bx[l];
+                    mem[n].d.out = (char*)d.gx + (size_t)t * d.gx_stride * esz;
+                    ++n;
+                }
+            const int rc = run_group(s, kind, mem, epi, n, stream, dry, ws_need, false);
+            if (rc) return rc;
+        }
+    }
+    return dry ? DVD_OK : launch_status();
+}
+
+int stack_backward(const dvd_gru_stack_desc* s, void* stream, bool dry, long long& ws_need) {
+    const int L = s->n_layers, T = s->layer[0].T, kind = stack_kind(s);
+    const long long M = (long long)s->layer[0].B * s->layer[0].H * s->layer[0].W;
+    const size_t esz = 2;
+    using T_ = bf16_t;
+    if (!dry)
+        for (int l = 0; l < L; ++l)
+            if (hipMemsetAsync(s->layer[l].carry, 0, (size_t)M * s->layer[l].hidden * sizeof(float), S_) != hipSuccess) return DVD_E_LAUNCH;
+    // gradient wrt layer l's state of step t: from outside the stack (top layer) or from the x-path of the layer above
+    auto dh_of = [&](int l, int t) -> const char* {
+        const size_t step = (size_t)M * s->layer[l].hidden * esz;
+        if (l == L - 1) return s->layer[l].dh_out ? (const char*)s->layer[l].dh_out + t * step : nullptr;
+        return (const char*)s->dh_mid[l + 1] + t * step;
+    };
+    for (int k = 0; k < T + 2 * (L - 1); ++k) {
+        Member mem[kMaxMember];
+        GruEpi epi[kMaxMember];
+        for (int phase = 0; phase < 2; ++phase) {                 // 0 = A group, 1 = B group
+            int n = 0;
+            for (int l = L - 1; l >= 0; --l) {
+                const dvd_gru_desc& d = s->layer[l];
+                const int t = T - 1 - (k - 2 * (L - 1 - l)), h = d.hidden;
+                if (t < 0 || t >= T) continue;
+                const size_t step = (size_t)M * h * esz;
+                const char* hprev = t > 0 ? (const char*)d.h_all + (t - 1) * step : (const char*)d.h0;
+                const char* u = (const char*)d.u_all + t * step; const char* r = (const char*)d.r_all + t * step;
+                const char* o = (const char*)d.o_all + t * step;
+                char* dg = (char*)d.dg + (size_t)t * M * 3 * h * esz;
+                const unsigned grid = cdiv(M * (h / 8), 256);
+                const bool has_prev = dry || t > 0 || d.h0 != nullptr;
+                if (phase == 0) {
+                    if (t == T - 1 && !dry)                       // first BPTT step of the layer: nothing upstream to ride on
+                        gru_bwd_out_kernel<T_><<<grid, 256, 0, S_>>>((const T_*)dh_of(l, t), d.carry, nullptr, 0, (const T_*)u, (const T_*)o,
+                                                                     (const T_*)hprev, (T_*)dg, 3 * h, M, h);
+                    if (!has_prev) {
+                        if (!dry) gru_bwd_r_kernel<T_><<<grid, 256, 0, S_>>>(d.carry, nullptr, 0, (const T_*)r, (const T_*)nullptr, (T_*)dg, 3 * h, M, h);
+                        continue;
+                    }
+                    GruEpi& g = epi[n];
+                    g = GruEpi{};
+                    g.mode = 3; g.h = h; g.ldg = 3 * h; g.r = const_cast<char*>(r); g.hprev = hprev; g.h32n = d.carry; g.o = dg;
+                    member_conv(mem[n], d, dg + (size_t)2 * h * esz, h, 3 * h, d.wd_o, d.wd_o_q, h, kind);
+                    mem[n].d.out = d.carry; mem[n].gate = 1;
+                    ++n;
+                } else {
+                    if (has_prev) {
+                        GruEpi& g = epi[n];
+                        g = GruEpi{};
+                        g.h = h; g.ldg = 3 * h; g.h32n = d.carry;
+                        g.mode = 4;
+                        if (t > 0) {                              // ... and the first half of step t - 1
+                            const size_t tp = (size_t)(t - 1);
+                            g.mode = 5;
+                            g.gx = dh_of(l, t - 1);
+                            g.u_in = (const char*)d.u_all + tp * step;
+                            g.hr = const_cast<char*>((const char*)d.o_all + tp * step);
+                            g.hprev = t - 1 > 0 ? (const char*)d.h_all + (tp - 1) * step : (const char*)d.h0;
+                            g.o = (char*)d.dg + tp * M * 3 * h * esz;
+                        }
+                        member_conv(mem[n], d, dg, 2 * h, 3 * h, d.wd_ur, d.wd_ur_q, h, kind);
+                        mem[n].d.out = d.carry; mem[n].gate = 1;
+                        ++n;
+                    }
+                    if (l > 0) {                                  // x-part backward-data: gradient reaching layer l-1's state of step t
+                        const int ci = s->cin[l];
+                        epi[n] = GruEpi{};
+                        member_conv(mem[n], d, dg, 3 * h, 3 * h, s->wdx[l], s->wdx_q[l], ci, kind);
+                        mem[n].d.out = (char*)s->dh_mid[l] + (size_t)t * M * ci * esz;
+                        mem[n].d.ldo = ci;
+                        if (s->layer[l - 1].dh_out) {
+                            mem[n].d.res = (const char*)s->layer[l - 1].dh_out + (size_t)t * M * ci * esz;
+                            mem[n].d.ldres = ci;
+                        }
+                        ++n;
+                    }
+                }
+            }
+            const int rc = run_group(s, kind, mem, epi, n, stream, dry, ws_need, true);
+            if (rc) return rc;
+        }
+    }
+    if (!dry)
+        for (int l = 0; l < L; ++l) {
+            const dvd_gru_desc& d = s->layer[l];
+            if (d.dh0) gru_dh0_kernel<<<cdiv(M * d.hidden, 256), 256, 0, S_>>>(d.carry, nullptr, 0, d.dh0, M, d.hidden);
+        }
+    return dry ? DVD_OK : launch_status();
+}
+
+}  // namespace
+
+extern "C" int dvd_convgru_stack_ok(const dvd_gru_stack_desc* d, int backward) {
+    dvd_gru_stack_desc t;
+    if (!d) return 0;
+    t = *d;
+    static float dummy;
+    if (!t.ws) t.ws = &dummy;                                     // (a geometry / pointer-completeness query: the workspace may not exist yet)
+    return stack_check(&t, backward != 0) == DVD_OK ? 1 : 0;
+}
+extern "C" long long dvd_convgru_stack_ws_floats(const dvd_gru_stack_desc* d) {
+    if (!d || d->n_layers < 1 || d->n_layers > DVD_GRU_STACK_MAX || stack_kind(d) < 0) return 0;
+    long long need = 0, nb = 0;
+    stack_forward(d, nullptr, true, need);
+    stack_backward(d, nullptr, true, nb);
+    if (nb > need) need = nb;
+    return need > 0 ? need : 1;
+}
+extern "C" int dvd_convgru_stack_forward(const dvd_gru_stack_desc* d, void* stream) {
+    const int rc = stack_check(d, false);
+    if (rc) return rc;
+    long long need = 0;
+    return stack_forward(d, stream, false, need);
+}
+extern "C" int dvd_convgru_stack_backward(const dvd_gru_stack_desc* d, void* stream) {
+    const int rc = stack_check(d, true);
+    if (rc) return rc;
+    long long need = 0;
+    return stack_backward(d, stream, false, need);
 }

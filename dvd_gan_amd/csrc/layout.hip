@@ -120,7 +120,17 @@ extern "C" int dvd_clip_to_tensor(const unsigned char* src, const unsigned char*
     return launch_status();
 }
 
-extern "C" int dvd_abi_version(void) { return 10; }
+extern "C" int dvd_abi_version(void) { return 11; }
+extern "C" int dvd_struct_size(int which) {
+    switch (which) {
+        case DVD_STRUCT_CONV: return (int)sizeof(dvd_conv_desc);
+        case DVD_STRUCT_WGRAD: return (int)sizeof(dvd_wgrad_desc);
+        case DVD_STRUCT_GRU: return (int)sizeof(dvd_gru_desc);
+        case DVD_STRUCT_SN_ITEM: return (int)sizeof(dvd_sn_item);
+        case DVD_STRUCT_GRU_STACK: return (int)sizeof(dvd_gru_stack_desc);
+        default: return -1;
+    }
+}
 extern "C" const char* dvd_strerror(int code) {
     switch (code) {
         case DVD_OK: return "ok";

@@ -346,6 +346,50 @@ class CondBatchNorm(Function):
 
 
 # ------------------------------------------------------------------ ConvGRU layer
+def _gru_gate_wgrads(x, dgx, dg, h_all, hr_all, h0, params, meta, weights):
+    """Weight / bias gradients of the three gates of one ConvGRU layer, batched over all T steps (autograd of ConvGRU.py:49-51).
+    x: the layer's input frames, dgx: d(pre-activation) as seen by the x-part (dg, or its sum over T for a shared input),
+    dg: [T*B,S,S,3h].  Returns (grads[3], dbias[3]): None entries when the kernels accumulated straight into the persistent
+    .grad buffers on the side stream."""
+    T, B, S1, S2, hid, cin, k = meta
+    dev = x.device
+    ctot = cin + hid
+    hflat = h_all.view(T * B, S1, S2, hid)
+    hrflat = hr_all.view(T * B, S1, S2, hid)
+    wparams = params[0::2]
+    bparams = params[1::2]
+    direct = _direct(*params)
+
+    def gate_wgrads(dws, dbs):
+        """dws[g] / dbs[g]: fp32 buffers (reference layouts) the kernels ACCUMULATE into"""
+        for g in range(3):
+            dw = dws[g]
+            K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot, dbias=dbs[g])
+            if h0 is not None:
+                # step 0 read the supplied state: h0 (update / reset) or h0 * r_0 = hr_all[0] (out gate)
+                K.conv_wgrad(h0 if g < 2 else hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin,
+                             dw_ci_tot=ctot, frames=B, x_row0=0, dy_row0=0)
+            if T > 1:
+                # h-part: steps 1..T-1 read h_{t-1} (update/reset) or h_{t-1}*r_t (out gate)
+                if g < 2:
+                    K.conv_wgrad(hflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
+                                 frames=(T - 1) * B, x_row0=0, dy_row0=B)
+                else:
+                    K.conv_wgrad(hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
+                                 frames=(T - 1) * B, x_row0=B, dy_row0=B)
+
+    if direct:
+        _side_run(lambda: gate_wgrads([p.grad for p in wparams], [p.grad for p in bparams]), x, dgx, dg, h_all, hr_all, h0)
+        return [None, None, None], [None, None, None]
+    db3 = torch.zeros(3 * hid, dtype=torch.float32, device=dev)
+    grads = [torch.zeros_like(w) for w in weights]
+    gate_wgrads(grads, [db3[g * hid:(g + 1) * hid] for g in range(3)])
+    return grads, [db3[:hid].clone(), db3[hid:2 * hid].clone(), db3[2 * hid:].clone()]
+
+
+GRU_STACK = _os.environ.get("DVD_GRU_STACK", "1") != "0"      # A/B aid: 0 = every ConvGRU layer by layer (ConvGRULayer)
+GRU_STACK_LAYER_POLICY = 0   # dvd_gru_stack_desc.layer_policy (tests set 1: the per-layer path's split-K factors -> bit-equal results)
+GRU_NS_CAP = 0               # dvd_gru_desc.ns_cap (tests: a common upper bound on the split-K factors of both paths)
 GRU_COMBINE_MAX = 0          # dvd_gru_desc.combine_max: 0 = the library's default policy (tests raise it to cover every slice count)
 
 
@@ -385,6 +429,8 @@ class ConvGRULayer(Function):
         ns1 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), 2 * hid, hid, ntaps)
         ns2 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, hid, ntaps)
         ns3 = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, 2 * hid, ntaps)
+        if GRU_NS_CAP > 0:
+            ns1, ns2, ns3 = min(ns1, GRU_NS_CAP), min(ns2, GRU_NS_CAP), min(ns3, GRU_NS_CAP)
         ws_n = lib.dvd_convgru_ws_floats(L.dt(x), B, S1, S2, hid, k)
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         d = L.GruDesc()
@@ -404,6 +450,7 @@ class ConvGRULayer(Function):
         d.ws = ws.data_ptr()
         d.tickets = L.gru_tickets(dev).data_ptr()
         d.combine_max = GRU_COMBINE_MAX
+        d.ns_cap = GRU_NS_CAP
         d.infer = int(infer)
         L.check(lib.dvd_convgru_layer_forward(C.byref(d), L.stream()))
         if infer:
@@ -431,6 +478,8 @@ class ConvGRULayer(Function):
         lib = L.lib()
         ns_o = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, hid, k * k)
         ns_ur = lib.dvd_conv_pick_nsplit(L.dt(x), C.c_longlong(M), hid, 2 * hid, k * k)
+        if GRU_NS_CAP > 0:
+            ns_o, ns_ur = min(ns_o, GRU_NS_CAP), min(ns_ur, GRU_NS_CAP)
         if K.wants_fragment_major(dtype, B, S1, S2, 2 * hid, hid, k, ns_ur):
             d.wd_ur_q = pur.fragment_major("wd").data_ptr()
         if K.wants_fragment_major(dtype, B, S1, S2, hid, hid, k, ns_o):
@@ -441,6 +490,7 @@ class ConvGRULayer(Function):
         d.ws, d.dh_out, d.dg, d.carry = ws.data_ptr(), dh.data_ptr(), dg.data_ptr(), carry.data_ptr()
         d.tickets = L.gru_tickets(dev).data_ptr()
         d.combine_max = GRU_COMBINE_MAX
+        d.ns_cap = GRU_NS_CAP
         dh0_32 = None
         if h0 is not None and ctx.needs_input_grad[9]:          # gradient wrt the supplied initial state (ConvGRU.py:104)
             dh0_32 = torch.empty(M, hid, dtype=torch.float32, device=dev)
@@ -449,43 +499,172 @@ class ConvGRULayer(Function):
         # ---- everything below is batched over all T steps ----
         dgx = K.sum_leading(dg.view(T, -1)).view(B, S1, S2, 3 * hid) if shared_x else dg
         dx = K.conv_forward(dgx, px.wd, (k, k), px.cip, wq=lambda: px.fragment_major("wd")) if ctx.needs_input_grad[0] else None
-        ctot = cin + hid
-        hflat = h_all.view(T * B, S1, S2, hid)
-        hrflat = hr_all.view(T * B, S1, S2, hid)
-        wparams = ctx.params[0::2]
-        bparams = ctx.params[1::2]
-        direct = _direct(*ctx.params)
-
-        def gate_wgrads(dws, dbs):
-            """dws[g] / dbs[g]: fp32 buffers (reference layouts) the kernels ACCUMULATE into"""
-            for g in range(3):
-                dw = dws[g]
-                K.conv_wgrad(x, dgx, dw, (k, k), hid, cin, dy_col=g * hid, dw_ci_off=0, dw_ci_tot=ctot, dbias=dbs[g])
-                if h0 is not None:
-                    # step 0 read the supplied state: h0 (update / reset) or h0 * r_0 = hr_all[0] (out gate)
-                    K.conv_wgrad(h0 if g < 2 else hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin,
-                                 dw_ci_tot=ctot, frames=B, x_row0=0, dy_row0=0)
-                if T > 1:
-                    # h-part: steps 1..T-1 read h_{t-1} (update/reset) or h_{t-1}*r_t (out gate)
-                    if g < 2:
-                        K.conv_wgrad(hflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
-                                     frames=(T - 1) * B, x_row0=0, dy_row0=B)
-                    else:
-                        K.conv_wgrad(hrflat, dg, dw, (k, k), hid, hid, dy_col=g * hid, dw_ci_off=cin, dw_ci_tot=ctot,
-                                     frames=(T - 1) * B, x_row0=B, dy_row0=B)
-
-        if direct:
-            _side_run(lambda: gate_wgrads([p.grad for p in wparams], [p.grad for p in bparams]), x, dgx, dg, h_all, hr_all, h0)
-            grads, dbl = [None, None, None], [None, None, None]
-        else:
-            db3 = torch.zeros(3 * hid, dtype=torch.float32, device=dev)
-            grads = [torch.zeros_like(w) for w in (wu, wr, wo)]
-            gate_wgrads(grads, [db3[g * hid:(g + 1) * hid] for g in range(3)])
-            dbl = [db3[:hid].clone(), db3[hid:2 * hid].clone(), db3[2 * hid:].clone()]
+        grads, dbl = _gru_gate_wgrads(x, dgx, dg, h_all, hr_all, h0, ctx.params, (T, B, S1, S2, hid, cin, k), (wu, wr, wo))
         dh0 = None
         if dh0_32 is not None:
             dh0 = dh0_32.view(h0.shape) if h0.dtype == torch.float32 else K.convert(dh0_32, h0.dtype).view(h0.shape)
         return (dx, grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2], None, None, dh0, None)
+
+
+class ConvGRUStack(Function):
+    """All layers and all T steps of a ConvGRU (ConvGRU.py:57-133) as a LAYER WAVEFRONT (dvd_convgru_stack_*, gru.hip): layer l
+    works on step t while layer l-1 works on step t + 2, the independent recurrent / x-part convolutions of the layers run as
+    grouped launches.  Arguments: x, T, shared_x, infer, n_layers, then per layer (wu, bu, wr, br, wo, bo), then per layer h0
+    (or None).  Returns the per-layer state sequences [T*B,S,S,h_l].  Same results as ConvGRULayer applied layer by layer."""
+
+    @staticmethod
+    def usable(x, cells):
+        """Host-side pre-check (the library's dvd_convgru_stack_ok has the last word inside forward)."""
+        if x.dtype != torch.bfloat16 or not GRU_STACK or len(cells) > L.GRU_STACK_MAX:
+            return False
+        S1, S2 = x.shape[1], x.shape[2]
+        if S1 != S2 or S1 & (S1 - 1) or not (S1 in (4, 8) or S1 >= 16):
+            return False
+        return all(c.kernel_size in (3, 5) and c.hidden_size % 8 == 0 for c in cells)
+
+    @staticmethod
+    def forward(ctx, x, T, shared_x, infer, nl, *flat):
+        dev, dtype = x.device, x.dtype
+        lib = L.lib()
+        wts = [flat[6 * l:6 * l + 6] for l in range(nl)]
+        h0s = list(flat[6 * nl:7 * nl])
+        B = x.shape[0] if shared_x else x.shape[0] // T
+        S1, S2 = x.shape[1], x.shape[2]
+        M = B * S1 * S2
+        sd = L.GruStackDesc()
+        sd.n_layers, sd.layer_policy, sd.run = nl, GRU_STACK_LAYER_POLICY, 0
+        keep, layers = [], []
+        inp = x
+        for l, (wu, bu, wr, br, wo, bo) in enumerate(wts):
+            hid, ctot, k = wu.shape[0], wu.shape[1], wu.shape[-1]
+            cin = ctot - hid
+            px = K.PackedConv(dtype, 3 * hid, cin, (k, k), dev, covered=True)
+            pur = K.PackedConv(dtype, 2 * hid, hid, (k, k), dev, covered=True)
+            po = K.PackedConv(dtype, hid, hid, (k, k), dev, covered=True)
+            for g, w in enumerate((wu, wr, wo)):
+                px.fill(w, co_off=g * hid, ci_off=0)
+            pur.fill(wu, co_off=0, ci_off=cin).fill(wr, co_off=hid, ci_off=cin)
+            po.fill(wo, ci_off=cin)
+            bias3 = torch.cat([bu, br, bo])
+            if l == 0:      # the first layer's input is known for every step: one batched convolution, off the chain
+                gx = K.conv_forward(x, px.wf, (k, k), 3 * hid, bias=bias3, wq=lambda: px.fragment_major("wf"))
+            else:           # written step by step inside the wavefront
+                gx = torch.empty(T * B, S1, S2, 3 * hid, dtype=dtype, device=dev)
+                sd.cin[l] = K.pad8(cin)
+                sd.wx[l], sd.wx_q[l], sd.bx[l] = px.wf.data_ptr(), px.fragment_major("wf").data_ptr(), bias3.data_ptr()
+            mk = lambda n=T: torch.empty(n, B, S1, S2, hid, dtype=dtype, device=dev)
+            if infer:
+                h_all, u_all, hr_all, r_all, o_all = mk(), mk(1), mk(1), None, None
+            else:
+                h_all, u_all, r_all, o_all, hr_all = mk(), mk(), mk(), mk(), mk()
+            h32 = torch.empty(2, M, hid, dtype=torch.float32, device=dev)
+            h0 = h0s[l]
+            d = sd.layer[l]
+            d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.dt(x), T, B, S1, S2, hid, k
+            d.gx_stride = 0 if (shared_x and l == 0) else M * 3 * hid
+            d.gx, d.w_ur, d.w_o = gx.data_ptr(), pur.wf.data_ptr(), po.wf.data_ptr()
+            d.w_ur_q, d.w_o_q = pur.fragment_major("wf").data_ptr(), po.fragment_major("wf").data_ptr()
+            d.h0 = h0.data_ptr() if h0 is not None else None
+            d.h_all, d.u_all, d.hr_all = h_all.data_ptr(), u_all.data_ptr(), hr_all.data_ptr()
+            d.r_all = r_all.data_ptr() if r_all is not None else None
+            d.o_all = o_all.data_ptr() if o_all is not None else None
+            d.h32 = h32.data_ptr()
+            d.tickets = L.gru_tickets(dev).data_ptr()
+            d.ns_cap = GRU_NS_CAP
+            d.infer = int(infer)
+            keep.append((gx, h32, bias3))
+            layers.append(dict(px=px, pur=pur, po=po, h_all=h_all, u_all=u_all, r_all=r_all, o_all=o_all, hr_all=hr_all,
+                               hid=hid, cin=cin, k=k))
+        ws = torch.empty(lib.dvd_convgru_stack_ws_floats(C.byref(sd)), dtype=torch.float32, device=dev)
+        sd.ws = ws.data_ptr()
+        if not lib.dvd_convgru_stack_ok(C.byref(sd), 0):
+            raise RuntimeError("ConvGRUStack: this stack is not served by the wavefront path (ConvGRUStack.usable disagrees with the library)")
+        L.check(lib.dvd_convgru_stack_forward(C.byref(sd), L.stream()))
+        outs = tuple(ly["h_all"].view(T * B, S1, S2, ly["hid"]) for ly in layers)
+        if infer:
+            return outs
+        ctx.set_materialize_grads(False)          # unused layer outputs arrive as None, not as zero tensors
+        saved = [x]
+        for l, ly in enumerate(layers):
+            saved += [wts[l][0], wts[l][2], wts[l][4], ly["h_all"], ly["u_all"], ly["r_all"], ly["o_all"], ly["hr_all"], h0s[l]]
+        ctx.save_for_backward(*saved)
+        ctx.params = [tuple(w) for w in wts]
+        ctx.packs = [(ly["px"], ly["pur"], ly["po"]) for ly in layers]
+        ctx.meta = (T, B, S1, S2, shared_x, nl, [(ly["hid"], ly["cin"], ly["k"]) for ly in layers])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *dhs):
+        T, B, S1, S2, shared_x, nl, dims = ctx.meta
+        sv = ctx.saved_tensors
+        x = sv[0]
+        per = [sv[1 + 9 * l:1 + 9 * (l + 1)] for l in range(nl)]
+        dev, dtype = x.device, x.dtype
+        lib = L.lib()
+        M = B * S1 * S2
+        sd = L.GruStackDesc()
+        sd.n_layers, sd.layer_policy, sd.run = nl, GRU_STACK_LAYER_POLICY, 0
+        dgs, carries, dh_mid, dh0_32, keep = [], [], [None] * nl, [None] * nl, []
+        for l in range(nl):
+            wu, wr, wo, h_all, u_all, r_all, o_all, hr_all, h0 = per[l]
+            hid, cin, k = dims[l]
+            px, pur, po = ctx.packs[l]
+            dg = torch.empty(T * B, S1, S2, 3 * hid, dtype=dtype, device=dev)
+            carry = torch.empty(M, hid, dtype=torch.float32, device=dev)
+            d = sd.layer[l]
+            d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = L.dt(x), T, B, S1, S2, hid, k
+            d.gx_stride = M * 3 * hid
+            d.gx = dg.data_ptr()                         # (not read by the backward pass; the descriptor check wants it non-null)
+            d.wd_ur, d.wd_o = pur.wd.data_ptr(), po.wd.data_ptr()
+            d.wd_ur_q, d.wd_o_q = pur.fragment_major("wd").data_ptr(), po.fragment_major("wd").data_ptr()
+            d.h0 = h0.data_ptr() if h0 is not None else None
+            d.h_all, d.u_all, d.r_all = h_all.data_ptr(), u_all.data_ptr(), r_all.data_ptr()
+            d.o_all, d.hr_all = o_all.data_ptr(), hr_all.data_ptr()
+            d.dg, d.carry = dg.data_ptr(), carry.data_ptr()
+            dh = dhs[l].contiguous() if dhs[l] is not None else None
+            d.dh_out = dh.data_ptr() if dh is not None else None
+            keep.append(dh)
+            d.tickets = L.gru_tickets(dev).data_ptr()
+            d.ns_cap = GRU_NS_CAP
+            if l > 0:
+                sd.cin[l] = K.pad8(cin)
+                sd.wdx[l], sd.wdx_q[l] = px.wd.data_ptr(), px.fragment_major("wd").data_ptr()
+                dh_mid[l] = torch.empty(T * B, S1, S2, K.pad8(cin), dtype=dtype, device=dev)
+                sd.dh_mid[l] = dh_mid[l].data_ptr()
+            if h0 is not None and ctx.needs_input_grad[5 + 6 * nl + l]:
+                dh0_32[l] = torch.empty(M, hid, dtype=torch.float32, device=dev)
+                d.dh0 = dh0_32[l].data_ptr()
+            dgs.append(dg)
+            carries.append(carry)
+        ws = torch.empty(lib.dvd_convgru_stack_ws_floats(C.byref(sd)), dtype=torch.float32, device=dev)
+        sd.ws = ws.data_ptr()
+        L.check(lib.dvd_convgru_stack_backward(C.byref(sd), L.stream()))
+        # ---- everything below is batched over all T steps ----
+        out = []
+        dx = None
+        for l in range(nl):
+            wu, wr, wo, h_all, u_all, r_all, o_all, hr_all, h0 = per[l]
+            hid, cin, k = dims[l]
+            px = ctx.packs[l][0]
+            dg = dgs[l]
+            if l == 0:
+                dgx = K.sum_leading(dg.view(T, -1)).view(B, S1, S2, 3 * hid) if shared_x else dg
+                if ctx.needs_input_grad[0]:
+                    dx = K.conv_forward(dgx, px.wd, (k, k), px.cip, wq=lambda: px.fragment_major("wd"))
+                xin = x
+            else:
+                dgx = dg
+                xin = per[l - 1][3].view(T * B, S1, S2, dims[l - 1][0])          # the layer below's states
+            grads, dbl = _gru_gate_wgrads(xin, dgx, dg, h_all, hr_all, h0, ctx.params[l], (T, B, S1, S2, hid, cin, k), (wu, wr, wo))
+            out += [grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2]]
+        dh0s = []
+        for l in range(nl):
+            h0 = per[l][8]
+            if dh0_32[l] is None:
+                dh0s.append(None)
+            else:
+                dh0s.append(dh0_32[l].view(h0.shape) if h0.dtype == torch.float32 else K.convert(dh0_32[l], h0.dtype).view(h0.shape))
+        return (dx, None, None, None, None, *out, *dh0s)
 
 
 # ------------------------------------------------------------------ attention / head / loss

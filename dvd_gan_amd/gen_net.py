@@ -59,6 +59,13 @@ class ConvGRU(nn.Module):
     def run(self, x, T, shared_x, hidden=None):
         """x: [T*B,S,S,C] t-major (or [B,S,S,C] if shared_x).  Returns the list of per-layer
         sequences [T*B,S,S,h_l] (the reference returns the last step's list per call)."""
+        if Fn.ConvGRUStack.usable(x, self.cells):      # layer wavefront: all layers in one pass of grouped launches
+            flat = []
+            for c in self.cells:
+                flat += [c.update_gate.weight, c.update_gate.bias, c.reset_gate.weight, c.reset_gate.bias, c.out_gate.weight,
+                         c.out_gate.bias]
+            flat += [None if hidden is None else hidden[i] for i in range(self.n_layers)]
+            return list(Fn.ConvGRUStack.apply(x, T, shared_x, not torch.is_grad_enabled(), self.n_layers, *flat))
         outs = []
         for i, cell in enumerate(self.cells):
             x = cell.run(x, T, shared_x and i == 0, None if hidden is None else hidden[i])

@@ -47,12 +47,20 @@ def lib():
         _lib.dvd_convgru_ws_floats.restype = C.c_longlong
         _lib.dvd_conv_thin_image_bytes.restype = C.c_longlong
         _lib.dvd_conv_thin_out_image_bytes.restype = C.c_longlong
+        _lib.dvd_convgru_stack_ws_floats.restype = C.c_longlong
         if _lib.dvd_abi_version() != ABI_VERSION:
             raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
+        # layout handshake: every descriptor mirror below must have the size the library was compiled with
+        for which, mirror in STRUCT_MIRRORS.items():
+            want = _lib.dvd_struct_size(which)
+            if want != C.sizeof(mirror):
+                _lib = None
+                raise RuntimeError(f"libdvdgan_hip.so: sizeof descriptor {which} is {want}, the ctypes mirror {mirror.__name__} has "
+                                   f"{C.sizeof(mirror)} bytes -- lib.py and include/dvdgan_hip.h disagree")
     return _lib
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 BN_NREP = 16            # DVD_BN_NREP of include/dvdgan_hip.h
 
 
@@ -103,10 +111,21 @@ class GruDesc(C.Structure):
                 ("dh_out", C.c_void_p), ("dg", C.c_void_p), ("carry", C.c_void_p), ("dh0", C.c_void_p),
                 ("infer", C.c_int),
                 ("w_ur_q", C.c_void_p), ("w_o_q", C.c_void_p), ("wd_ur_q", C.c_void_p), ("wd_o_q", C.c_void_p),
-                ("tickets", C.c_void_p), ("combine_max", C.c_int)]
+                ("tickets", C.c_void_p), ("combine_max", C.c_int), ("ns_cap", C.c_int)]
 
 
 GRU_TICKETS = 8192                      # == DVD_GRU_TICKETS
+
+
+GRU_STACK_MAX = 4                       # == DVD_GRU_STACK_MAX
+
+
+class GruStackDesc(C.Structure):        # == dvd_gru_stack_desc
+    _fields_ = [("n_layers", C.c_int), ("layer_policy", C.c_int), ("run", C.c_int), ("cin", C.c_int * GRU_STACK_MAX),
+                ("layer", GruDesc * GRU_STACK_MAX),
+                ("wx", C.c_void_p * GRU_STACK_MAX), ("wx_q", C.c_void_p * GRU_STACK_MAX), ("bx", C.c_void_p * GRU_STACK_MAX),
+                ("wdx", C.c_void_p * GRU_STACK_MAX), ("wdx_q", C.c_void_p * GRU_STACK_MAX), ("dh_mid", C.c_void_p * GRU_STACK_MAX),
+                ("ws", C.c_void_p)]
 
 
 class SnItem(C.Structure):              # == dvd_sn_item
@@ -114,3 +133,7 @@ class SnItem(C.Structure):              # == dvd_sn_item
                 ("wf", C.c_void_p), ("wd", C.c_void_p), ("h", C.c_int), ("w", C.c_int),
                 ("dtype", C.c_int), ("cout", C.c_int), ("cin", C.c_int), ("ntaps", C.c_int), ("cip", C.c_int), ("cop", C.c_int),
                 ("blk_wtu", C.c_int), ("blk_wv", C.c_int), ("blk_pack", C.c_int), ("pad_", C.c_int)]
+
+
+# dvd_struct_size(which) -> ctypes mirror (DVD_STRUCT_* of include/dvdgan_hip.h)
+STRUCT_MIRRORS = {0: ConvDesc, 1: WgradDesc, 2: GruDesc, 3: SnItem, 4: GruStackDesc}

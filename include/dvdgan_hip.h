@@ -214,6 +214,8 @@ typedef struct {
     unsigned* tickets;
     int combine_max;           /* largest split-K factor combined in-launch; 0 = the library's measured default (4: beyond that the
                                   gate kernel, which spreads the slab reads over the whole chip, is faster)                       */
+    int ns_cap;                /* > 0: upper bound on the split-K factor of the recurrent convolutions (tests: the same factors in
+                                  the layer-by-layer and the wavefront path -> bit-equal results); 0 = the measured policy        */
 } dvd_gru_desc;
 #define DVD_GRU_TICKETS 8192
 int dvd_convgru_layer_forward(const dvd_gru_desc* d, void* stream);
@@ -221,6 +223,45 @@ int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream);
 /* floats the caller provides as dvd_gru_desc.ws for a layer of this shape (slabs of whole output tiles) */
 long long dvd_convgru_ws_floats(int dtype, int B, int H, int W, int hidden, int k);
 int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int ntaps);
+
+/* ------------------------------------------------------------------------------------------
+ * A whole ConvGRU (Module/ConvGRU.py:57-133: n_layers chained cells, layer l's input at step t = layer l-1's new state)
+ * as a LAYER WAVEFRONT: layer l works on step t while layer l-1 works on step t + 2, so the recurrent convolutions of all
+ * layers -- and the x-part convolutions of the layers above the first, now one per step -- are independent of each other
+ * and run as GROUPED launches (several convolutions in one grid, their tiles interleaved).  A one-round launch of one
+ * layer runs its workgroups in lock step (main loops, then the HBM-bound gate epilogues, overlapping with nothing); in a
+ * grouped launch one tile's epilogue runs under another's main loop and the 4 x 4 / 8 x 8 stages issue 2 instead of 6-12
+ * dependent launches per step.  Results equal dvd_convgru_layer_* applied layer by layer (bit-equal when the split-K
+ * factors are the same: `layer_policy`).  bf16, square power-of-two frames of 4, 8 or >= 16 pixels, 3 x 3 / 5 x 5 filters,
+ * fragment-major weight images required: dvd_convgru_stack_ok() says whether a stack is served; callers fall back to the
+ * per-layer entry points otherwise.
+ * ---------------------------------------------------------------------------------------- */
+#define DVD_GRU_STACK_MAX 4
+typedef struct {
+    int n_layers;                                   /* 1 .. DVD_GRU_STACK_MAX                                          */
+    int layer_policy;                               /* 0: split-K factors chosen per grouped launch; 1: dvd_conv_pick_nsplit per
+                                                       convolution, x-part unsplit (the per-layer path's arithmetic, for tests) */
+    int run;                                        /* tiles per pattern entry of a grouped launch; 0 = default           */
+    int cin[DVD_GRU_STACK_MAX];                     /* stored (padded) input channels of layer l's x-part; l >= 1: hidden of l-1 */
+    dvd_gru_desc layer[DVD_GRU_STACK_MAX];          /* as for dvd_convgru_layer_*: same dtype, T, B, H, W in every layer.
+                                                       layer[l >= 1].gx ([T][M][3 hidden_l], gx_stride = M * 3 hidden_l) is
+                                                       WRITTEN by the forward call; layer[l].ws is not used (`ws` below);
+                                                       layer[0].tickets serves the whole stack; backward: layer[n-1].dh_out =
+                                                       gradient wrt the top layer's states, layer[l < n-1].dh_out = optional
+                                                       gradient wrt that layer's states from outside the stack, or NULL        */
+    const void* wx[DVD_GRU_STACK_MAX];              /* l >= 1: x-part forward pack [k*k][3 hidden_l][cin_l] ...               */
+    const void* wx_q[DVD_GRU_STACK_MAX];            /* ... its fragment-major image ...                                      */
+    const float* bx[DVD_GRU_STACK_MAX];             /* ... and bias [3 hidden_l] (update | reset | out)                      */
+    const void* wdx[DVD_GRU_STACK_MAX];             /* backward, l >= 1: x-part backward-data pack [k*k][cin_l][3 hidden_l]   */
+    const void* wdx_q[DVD_GRU_STACK_MAX];           /* ... its fragment-major image                                          */
+    void* dh_mid[DVD_GRU_STACK_MAX];                /* backward, l >= 1: out [T][M][cin_l] = gradient reaching layer l-1's states
+                                                       (x-path of layer l + layer[l-1].dh_out)                               */
+    float* ws;                                      /* dvd_convgru_stack_ws_floats(d) floats (split-K slabs of the grouped launches) */
+} dvd_gru_stack_desc;
+int dvd_convgru_stack_ok(const dvd_gru_stack_desc* d, int backward);
+long long dvd_convgru_stack_ws_floats(const dvd_gru_stack_desc* d);
+int dvd_convgru_stack_forward(const dvd_gru_stack_desc* d, void* stream);
+int dvd_convgru_stack_backward(const dvd_gru_stack_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batch norm statistics + conditional batch norm (Module/Normalization.py:78-88; F.batch_norm +

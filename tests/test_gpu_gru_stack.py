@@ -1,0 +1,122 @@
+"""The layer wavefront over a ConvGRU stack (dvd_convgru_stack_*, gru.hip; functional.ConvGRUStack) against the layer-by-layer
+path (dvd_convgru_layer_*, functional.ConvGRULayer) it replaces in bf16 mode (Module/ConvGRU.py:57-133, Generator.py:87-97):
+
+  * with the per-layer path's split-K factors (`layer_policy` = 1) the two paths execute the same arithmetic per output element
+    -- per-step instead of batched x-part / backward-data convolutions, grouped instead of single launches, other tile shapes --
+    so every state of every layer and the input gradient must be BIT-EQUAL, the weight gradients equal up to the fp32 atomics of
+    the narrow test layers;
+  * with the production policy (split-K factors chosen per grouped launch) only fp32 summation order changes.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CASES = [   # T, B, S, cin, hidden sizes, kernel sizes, shared input (first ConvGRU of the generator), supplied initial states, split-K cap
+    (5, 8, 4, 16, [16, 32, 16], [3, 5, 3], False, None, 1),
+    (5, 8, 4, 32, [64, 64, 64], [3, 5, 3], True, (True, False, True), 2),
+    (5, 4, 8, 16, [16, 32, 16], [3, 5, 3], False, None, 1),
+    (4, 4, 8, 32, [64, 128, 64], [3, 5, 3], False, (False, True, True), 2),
+    (4, 2, 16, 16, [16, 32, 16], [3, 5, 5], False, None, 1),
+    (3, 3, 16, 16, [64, 64, 64], [3, 5, 3], False, (True, True, True), 2),
+    (3, 2, 32, 8, [8, 16, 8], [3, 5, 5], False, None, 1),
+    (3, 1, 32, 8, [16, 8], [5, 3], False, None, 1),            # two layers
+    (2, 2, 16, 8, [16], [5], False, None, 1),                  # one layer: nothing to overlap, same entry point
+]
+
+
+def _build(case):
+    from dvd_gan_amd.gen_net import ConvGRU
+    T, B, S, cin, hids, ks, shared, h0, _ = case
+    torch.manual_seed(5)
+    gru = ConvGRU(cin, hids, ks, len(hids))
+    for p in gru.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.1)
+    x = torch.randn((B if shared else T * B), cin, S, S)
+    gys = [torch.randn(T * B, h, S, S) for h in hids]
+    h0s = None if h0 is None else [torch.randn(B, h, S, S) * 0.5 if on else None for h, on in zip(hids, h0)]
+    return gru.to(DEV), x, gys, h0s
+
+
+def _run(gru, case, x, gys, h0s, all_layers):
+    from dvd_gan_amd import functional as Fn
+    T, B, S, cin, hids, ks, shared = case[:7]
+    for p in gru.parameters():
+        p.grad = None
+    xg = x.to(DEV).requires_grad_(True)
+    hg = None if h0s is None else [None if h is None else h.to(DEV).requires_grad_(True) for h in h0s]
+    hcl = None if hg is None else [None if h is None else Fn.ToChannelsLast.apply(h, torch.bfloat16, None) for h in hg]
+    outs = gru.run(Fn.ToChannelsLast.apply(xg, torch.bfloat16, None), T, shared, hcl)
+    ys = [Fn.FromChannelsLast.apply(o, h, None) for o, h in zip(outs, hids)]
+    loss = sum((y * gy.to(DEV)).sum() for y, gy in zip(ys, gys)) if all_layers else (ys[-1] * gys[-1].to(DEV)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    res = {"ys": [y.detach().clone() for y in ys], "dx": xg.grad.clone(),
+           "dh0": [] if hg is None else [h.grad.clone() for h in hg if h is not None],
+           "dw": [p.grad.clone() for p in gru.parameters()]}
+    return res
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"T{c[0]}B{c[1]}S{c[2]}h{'-'.join(map(str, c[4]))}{'s' if c[6] else ''}{'i' if c[7] else ''}")
+def test_wavefront_equals_layer_by_layer_bitwise(case, monkeypatch):
+    from dvd_gan_amd import functional as Fn
+    from dvd_gan_amd import lib as L
+    gru, x, gys, h0s = _build(case)
+    monkeypatch.setattr(Fn, "GRU_COMBINE_MAX", 8)               # layer path: every split factor combined in-launch, like the stack's
+    monkeypatch.setattr(Fn, "GRU_STACK_LAYER_POLICY", 1)
+    monkeypatch.setattr(Fn, "GRU_NS_CAP", case[8])               # ... and the same factors (at most the channel chunks of these narrow layers)
+    monkeypatch.setattr(Fn, "GRU_STACK", True)
+    assert Fn.ConvGRUStack.usable(torch.empty(1, case[2], case[2], 8, dtype=torch.bfloat16), gru.cells)
+    new = _run(gru, case, x, gys, h0s, all_layers=False)
+    assert int(L.gru_tickets(torch.device(DEV, torch.cuda.current_device())).abs().sum()) == 0
+    again = _run(gru, case, x, gys, h0s, all_layers=False)
+    monkeypatch.setattr(Fn, "GRU_STACK", False)
+    old = _run(gru, case, x, gys, h0s, all_layers=False)
+    for l, (a, b, c) in enumerate(zip(new["ys"], old["ys"], again["ys"])):
+        assert torch.equal(a, b), f"layer {l}: states differ (rel {_rel(a, b):.3e})"
+        assert torch.equal(a, c), f"layer {l}: not reproducible"
+    assert torch.equal(new["dx"], old["dx"]), f"dx differs (rel {_rel(new['dx'], old['dx']):.3e})"
+    for a, b in zip(new["dh0"], old["dh0"]):
+        assert torch.equal(a, b)
+    for (k, _), a, b in zip(gru.named_parameters(), new["dw"], old["dw"]):
+        assert _rel(a, b) < 1e-5, (k, _rel(a, b))               # same kernels on bit-equal operands; fp32 atomics in the narrow layers
+
+
+@pytest.mark.parametrize("case", CASES[:7:2], ids=lambda c: f"T{c[0]}B{c[1]}S{c[2]}")
+def test_wavefront_production_policy_and_outer_gradients(case, monkeypatch):
+    """Split-K factors chosen per grouped launch, and a loss on EVERY layer's states (the gradient from outside the stack rides
+    in the epilogue of the x-part backward-data convolution, in fp32, where autograd adds two bf16 tensors)."""
+    from dvd_gan_amd import functional as Fn
+    gru, x, gys, h0s = _build(case)
+    monkeypatch.setattr(Fn, "GRU_STACK", True)
+    new = _run(gru, case, x, gys, h0s, all_layers=True)
+    monkeypatch.setattr(Fn, "GRU_STACK", False)
+    old = _run(gru, case, x, gys, h0s, all_layers=True)
+    for a, b in zip(new["ys"], old["ys"]):
+        assert _rel(a, b) < 4e-3
+    assert _rel(new["dx"], old["dx"]) < 1e-2
+    for a, b in zip(new["dh0"], old["dh0"]):
+        assert _rel(a, b) < 1e-2
+    for (k, _), a, b in zip(gru.named_parameters(), new["dw"], old["dw"]):
+        assert _rel(a, b) < 1e-2, (k, _rel(a, b))
+
+
+def test_wavefront_inference_form(monkeypatch):
+    """Under torch.no_grad() (the sampling path, trainer.py:323-334) nothing is kept for a backward pass: same states."""
+    from dvd_gan_amd import functional as Fn
+    case = CASES[4]
+    gru, x, gys, h0s = _build(case)
+    T, B, S, cin, hids, ks, shared = case[:7]
+    monkeypatch.setattr(Fn, "GRU_STACK", True)
+    xc = Fn.ToChannelsLast.apply(x.to(DEV), torch.bfloat16, None)
+    a = gru.run(xc, T, shared)
+    with torch.no_grad():
+        b = gru.run(xc, T, shared)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -145,7 +145,71 @@ def parts(iters, B, T, n, sel):
             print(f"{LAYERS[i][0]} {fn_name[19:]:9s}: whole batch {t1:7.2f} ms   {n} parts on {n} streams {t2:7.2f} ms   ({100 * (1 - t2 / t1):5.1f} % saved)", flush=True)
 
 
+def stack(iters, B, T, sel, run=0, policy=0):
+    """Whole ConvGRUs: the layer wavefront (dvd_convgru_stack_*) against the layer-by-layer path INCLUDING what the wavefront
+    absorbs -- the batched x-part convolutions of layers 1, 2 (forward) and their batched backward-data convolutions."""
+    dev, dt = "cuda", torch.bfloat16
+    lib = L.lib()
+    lib.dvd_convgru_stack_ws_floats.restype = C.c_longlong
+    tot = [0.0, 0.0, 0.0, 0.0]
+    for gi in sel:
+        lays = LAYERS[3 * gi:3 * gi + 3]
+        S = lays[0][1]
+        M = B * S * S
+        descs, keeps, pxs, gxs, dhm = [], [], [], [], []
+        for (name, S_, cin, hid, k) in lays:
+            d, keep = setup(name, S_, cin, hid, k, B, T, dev, dt, lib)
+            px = K.PackedConv(dt, 3 * hid, cin, (k, k), dev).fill(torch.randn(3 * hid, cin, k, k, device=dev) * (0.5 / (cin * k * k) ** 0.5))
+            descs.append(d); keeps.append(keep); pxs.append(px)
+            gxs.append(keep[0]); dhm.append(torch.empty(T * B, S, S, cin, dtype=dt, device=dev))
+        bias = [torch.zeros(3 * l[3], device=dev) for l in lays]
+        sd = L.GruStackDesc()
+        sd.n_layers, sd.layer_policy, sd.run = 3, policy, run
+        for l in range(3):
+            C.memmove(C.byref(sd.layer[l]), C.byref(descs[l]), C.sizeof(L.GruDesc))
+            if l:
+                sd.cin[l] = lays[l][2]
+                sd.wx[l], sd.wx_q[l], sd.bx[l] = pxs[l].wf.data_ptr(), pxs[l].fragment_major("wf").data_ptr(), bias[l].data_ptr()
+                sd.wdx[l], sd.wdx_q[l] = pxs[l].wd.data_ptr(), pxs[l].fragment_major("wd").data_ptr()
+                sd.dh_mid[l] = dhm[l].data_ptr()
+        sd.layer[0].dh_out = None
+        sd.layer[1].dh_out = None
+        ws = torch.empty(lib.dvd_convgru_stack_ws_floats(C.byref(sd)), dtype=torch.float32, device=dev)
+        sd.ws = ws.data_ptr()
+        assert lib.dvd_convgru_stack_ok(C.byref(sd), 0) and lib.dvd_convgru_stack_ok(C.byref(sd), 1)
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        hs = [keeps[l][3].view(T * B, S, S, lays[l][3]) for l in range(3)]           # h_all of every layer
+        dgs = [keeps[l][-3].view(T * B, S, S, 3 * lays[l][3]) for l in range(3)]
+
+        def layer_fwd():
+            for l in range(3):
+                if l:
+                    K.conv_forward(hs[l - 1], pxs[l].wf, (lays[l][4],) * 2, 3 * lays[l][3], bias=bias[l], out=gxs[l].view(T * B, S, S, -1),
+                                   wq=lambda: pxs[l].fragment_major("wf"))
+                L.check(lib.dvd_convgru_layer_forward(C.byref(descs[l]), st()))
+
+        def layer_bwd():
+            for l in (2, 1, 0):
+                L.check(lib.dvd_convgru_layer_backward(C.byref(descs[l]), st()))
+                if l:
+                    K.conv_forward(dgs[l], pxs[l].wd, (lays[l][4],) * 2, pxs[l].cip, out=dhm[l], wq=lambda: pxs[l].fragment_major("wd"))
+        t_lf = timed(layer_fwd, iters)
+        t_sf = timed(lambda: L.check(lib.dvd_convgru_stack_forward(C.byref(sd), st())), iters)
+        t_lb = timed(layer_bwd, iters)
+        t_sb = timed(lambda: L.check(lib.dvd_convgru_stack_backward(C.byref(sd), st())), iters)
+        for i, v in enumerate((t_lf, t_sf, t_lb, t_sb)):
+            tot[i] += v
+        print(f"gru{gi} S={S:2d}: forward layers {t_lf:7.2f} ms  wavefront {t_sf:7.2f} ms ({100 * (1 - t_sf / t_lf):5.1f} % saved)   "
+              f"backward layers {t_lb:7.2f} ms  wavefront {t_sb:7.2f} ms ({100 * (1 - t_sb / t_lb):5.1f} % saved)", flush=True)
+    print(f"total: forward {tot[0]:.2f} -> {tot[1]:.2f} ms   backward {tot[2]:.2f} -> {tot[3]:.2f} ms   sum {tot[0] + tot[2]:.2f} -> {tot[1] + tot[3]:.2f} ms")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "stack":
+        sel = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2] else range(4)
+        run = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+        policy = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+        return stack(3, 64, 48, sel, run, policy)
     if len(sys.argv) > 1 and sys.argv[1] == "parts":
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
         sel = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(LAYERS))
