@@ -29,6 +29,43 @@ def test_library_exports_every_declared_symbol():
     assert b"unsupported shape" in lib.dvd_strerror(-2)
 
 
+def test_descriptor_layouts_match_the_library():
+    """Layout handshake: sizeof() of every descriptor struct as the .so was compiled == the ctypes mirror in
+    dvd_gan_amd/lib.py == (for dvd_conv_desc) the stub INTEGRATION.md section 2 prints.  Changing a descriptor in the header without
+    touching lib.py or the document fails here, on the CPU."""
+    import ctypes as C
+    from dvd_gan_amd import lib as L
+    lib = L.lib()
+    assert set(L.STRUCT_MIRRORS) == {0, 1, 2, 3, 4}
+    for which, mirror in L.STRUCT_MIRRORS.items():
+        assert lib.dvd_struct_size(which) == C.sizeof(mirror), (which, mirror.__name__)
+    assert lib.dvd_struct_size(99) == -1
+    # the struct literally as INTEGRATION.md prints it
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a = doc.index("class ConvDesc(C.Structure):")
+    b = doc.index("assert lib.dvd_abi_version()", a)
+    ns = {"C": C}
+    exec(doc[a:b], ns)
+    stub = ns["ConvDesc"]
+    assert C.sizeof(stub) == lib.dvd_struct_size(0)
+    assert [(n, getattr(stub, n).offset) for n, _ in stub._fields_] == [(n, getattr(L.ConvDesc, n).offset) for n, _ in L.ConvDesc._fields_]
+    assert "dvd_abi_version() == %d" % L.ABI_VERSION in doc
+    # a mirror that lost its tail is refused at load
+    saved = L.STRUCT_MIRRORS[0]
+
+    class Short(C.Structure):
+        _fields_ = L.ConvDesc._fields_[:-2]
+    try:
+        L.STRUCT_MIRRORS[0] = Short
+        L._lib = None
+        with pytest.raises(RuntimeError, match="sizeof descriptor 0"):
+            L.lib()
+    finally:
+        L.STRUCT_MIRRORS[0] = saved
+        L._lib = None
+        L.lib()
+
+
 def test_argument_validation_needs_no_gpu():
     from dvd_gan_amd import lib as L
     lib = L.lib()
@@ -124,3 +161,41 @@ def test_condition_index_table_reproduces_quirk1():
     for t in range(T):
         for b in range(B):
             assert int(samp[t * B + b]) == int(cond_rows[b * T + t])
+
+
+def test_convgru_stack_queries_need_no_gpu():
+    """dvd_convgru_stack_ok / dvd_convgru_stack_ws_floats (layer wavefront over a ConvGRU, Module/ConvGRU.py:57-133) are pure host
+    logic: which stacks the grouped-launch path serves, and how much split-K slab space its schedule needs."""
+    import ctypes as C
+    from dvd_gan_amd import lib as L
+    lib = L.lib()
+
+    def stack(S, hids, ks, dtype=L.BF16, B=64, T=48, cin0=256):
+        sd = L.GruStackDesc()
+        sd.n_layers = len(hids)
+        for l, (h, k) in enumerate(zip(hids, ks)):
+            d = sd.layer[l]
+            d.dtype, d.T, d.B, d.H, d.W, d.hidden, d.k = dtype, T, B, S, S, h, k
+            d.gx_stride = B * S * S * 3 * h
+            for f in ("gx", "w_ur", "w_o", "w_ur_q", "w_o_q", "wd_ur", "wd_o", "wd_ur_q", "wd_o_q", "h_all", "u_all", "r_all", "o_all",
+                      "hr_all", "tickets", "dg", "carry"):
+                setattr(d, f, 1)                     # never dereferenced by the queries
+            if l:
+                sd.cin[l] = hids[l - 1]
+                sd.wx[l] = sd.wx_q[l] = sd.bx[l] = sd.wdx[l] = sd.wdx_q[l] = sd.dh_mid[l] = 1
+        return sd
+
+    ok = lambda sd, bwd=0: lib.dvd_convgru_stack_ok(C.byref(sd), bwd)
+    g3 = stack(32, [128, 256, 128], [3, 5, 5])
+    assert ok(g3) == 1 and ok(g3, 1) == 1
+    assert ok(stack(4, [256, 512, 256], [3, 5, 3])) == 1 and ok(stack(8, [256, 512, 256], [3, 5, 3])) == 1
+    assert ok(stack(12, [256, 512, 256], [3, 5, 3])) == 0          # not a power of two
+    assert ok(stack(32, [128, 256, 128], [3, 7, 5])) == 0          # 7 x 7 taps
+    assert ok(stack(32, [128, 256, 128], [3, 5, 5], dtype=L.F32)) == 0
+    bad = stack(32, [128, 256, 128], [3, 5, 5])
+    bad.wx_q[1] = None
+    assert ok(bad) == 0 and ok(bad, 1) == 1                        # the forward pass needs the x-part image, the backward pass does not
+    assert lib.dvd_convgru_stack_ws_floats(C.byref(g3)) >= 1       # one-round groups at 32 x 32: nothing is split
+    small = lib.dvd_convgru_stack_ws_floats(C.byref(stack(4, [256, 512, 256], [3, 5, 3])))
+    assert small > 16384 and small % 16384 == 0                    # 4 x 4 frames: split-K slabs of whole 128 x 128 tiles
+    assert lib.dvd_convgru_stack_forward(C.byref(stack(12, [256], [3])), None) == -2
