@@ -183,6 +183,7 @@ def test_convgru_stack_queries_need_no_gpu():
             if l:
                 sd.cin[l] = hids[l - 1]
                 sd.wx[l] = sd.wx_q[l] = sd.bx[l] = sd.wdx[l] = sd.wdx_q[l] = sd.dh_mid[l] = 1
+        sd.ws = 1
         return sd
 
     ok = lambda sd, bwd=0: lib.dvd_convgru_stack_ok(C.byref(sd), bwd)
