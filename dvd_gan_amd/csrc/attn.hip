@@ -148,17 +148,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const T* kv, int ldk
     const int f = blockIdx.y, i0 = blockIdx.x * QB, tid = threadIdx.x;
     const T* kf = kv + (size_t)f * Nk * ldk;
     const float g = *gamma;
-    // dgamma partial: sum dy * att_out over this block's rows
-    float dgp = 0.f;
-    for (int idx = tid; idx < QB * C; idx += 256) {
-        const int i = i0 + idx / C, c = idx % C;
-        if (i < N) {
-            const size_t o = ((size_t)f * N + i) * ldx + c;
-            dgp += ldf(dy + o) * ldf(att_out + o);
-        }
-    }
-    dgp = blk_sum(dgp, sh);
-    if (tid == 0 && dgamma) atomicAdd(dgamma, dgp);
+    (void)dgamma;                                  // dgamma: attn_dgamma_kernel below (fixed summation order)
     // dA[i][j] = gamma * sum_c dy[i][c] v[j][c]: the block's QB rows of dy are staged in LDS as
     // floats; thread j streams its v row with 16-byte loads and keeps QB accumulators.
     float* dyl = S + QB * Nk;                       // [QB][C]
@@ -281,6 +271,32 @@ static int attention_fwd(int dtype, const void* q, int ldq, int dq, const void* 
     return launch_status();
 }
 
+// dgamma += sum over all rows and channels of dy * att_out, ONE block in a fixed order (per-block partial sums added with fp32
+// atomics made the gradient of gamma differ from run to run)
+template <typename T>
+__global__ __launch_bounds__(1024) void attn_dgamma_kernel(const T* dy, const T* att_out, long long rows, int C, int ldx, float* dgamma) {
+    __shared__ float shw[16];
+    const int cg = C / 8;
+    float a = 0.f;
+    for (long long i = threadIdx.x; i < rows * cg; i += 1024) {
+        const long long r = i / cg;
+        const int c = (int)(i - r * cg) * 8;
+        float u[8], v[8];
+        load8<T>(dy + (size_t)r * ldx + c, u);
+        load8<T>(att_out + (size_t)r * ldx + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += u[k] * v[k];
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += shw[w];
+        *dgamma += t;
+    }
+}
+
 static int attention_bwd(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff, const void* dy,
                          int ldx, int C, const float* gamma, const void* att_out, const float* A, float* dS, void* dqo,
                          void* dkv, float* dgamma, long long frames, int N, int Nk, void* stream) {
@@ -299,6 +315,7 @@ static int attention_bwd(int dtype, const void* q, int ldq, int dq, const void* 
     } while (0)
     if (qb == 16) ATT_BWD(16); else ATT_BWD(8);
 #undef ATT_BWD
+    if (dgamma) BY_DTYPE(dtype, attn_dgamma_kernel<T><<<1, 1024, 0, S_>>>((const T*)dy, (const T*)att_out, frames * N, C, ldx, dgamma));
     return launch_status();
 }
 

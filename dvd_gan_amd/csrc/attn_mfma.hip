@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const bf16_t* qkv,
             for (int j = 0; j < 2; ++j) dq = mma(tr_frag(Kl, RSK, kb * 32 + 16 * j + 4 * h, 0, lane), pack8(ds + 8 * j), dq);
         }
     }
-    float dgp = 0.f;
     if (active) {
         bf16_t* dst = dqkv + ((size_t)f * N + q) * ldq;
         uint2 a, b;
@@ -203,10 +202,24 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const bf16_t* qkv,
         b.x = pack2_bf16(dq[4], dq[5]); b.y = pack2_bf16(dq[6], dq[7]);          // d = 8 + 4 h + {0..3}
         *reinterpret_cast<uint2*>(dst + 4 * h) = a;
         *reinterpret_cast<uint2*>(dst + 8 + 4 * h) = b;
-        if (h == 0) { Dout[(size_t)f * N + q] = Dp; dgp = Dp; }
+        if (h == 0) Dout[(size_t)f * N + q] = Dp;
     }
-    dgp = wave_sum(dgp);
-    if (lane == 0 && dgamma && dgp != 0.f) atomicAdd(dgamma, dgp);
+}
+
+// dgamma += sum over all (frame, query) of D, in a fixed order (one block; the query pass leaves D complete) -- the first form
+// added per-wave partial sums with fp32 atomics, whose order changed from run to run
+__global__ __launch_bounds__(1024) void attn_dgamma_kernel(const float* D, long long n, float* dgamma) {
+    __shared__ float sh[16];
+    float a = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) a += D[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        *dgamma += t;
+    }
 }
 
 // ---------------------------------------------------------------------------- backward, key pass
@@ -327,5 +340,6 @@ extern "C" int dvd_attention_mfma_backward(const void* qkv, int ldq, const void*
     } while (0)
     if (C == 128) BWD(4); else if (C == 64) BWD(2); else BWD(1);
 #undef BWD
+    if (dgamma) attn_dgamma_kernel<<<1, 1024, 0, S_>>>(D, frames * N, dgamma);
     return launch_status();
 }

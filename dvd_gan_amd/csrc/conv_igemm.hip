@@ -12,8 +12,6 @@
 //   bf16 : v_mfma_f32_32x32x16_bf16   (A: lane l holds row l&31, k = 8*(l>>5)..+7)
 //   f32  : v_mfma_f32_32x32x2_f32     (A: lane l holds row l&31, k = l>>5)        exact mode
 //   C/D  : col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-// Environment switches read here are for A/B measurements only (DVD_CONV_HALO, DVD_WG_ROW, DVD_WG_TGT, ...);
-// none of them changes results.
 #include "conv_common.h"
 #include "prof.h"
 
@@ -683,13 +681,11 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
     // halo-staged kernel: square 3x3 / 5x5 (x3) filters on frames at least one 16 x 16 patch large.  It runs as
     // 4-wave workgroups only: with the activation DMAs gone, two 256 x 128 workgroups per CU beat one 8-wave
     // 256 x 256 workgroup (1.13-1.34 vs 0.86-1.12 PF/s on the S = 16 / 32 shapes of config C2).
-    static const int use_halo = getenv("DVD_CONV_HALO") ? atoi(getenv("DVD_CONV_HALO")) : 1;
-    const bool halo = use_halo && pow2 && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->W >= 16 && d->H >= 16 &&
+    const bool halo = pow2 && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->W >= 16 && d->H >= 16 &&
                       p.nsplit <= p.kchunks * d->kt;
     // frames of 4 x 4 / 8 x 8 pixels (bf16, 2-D taps, no upsample): whole-frame footprints in LDS, weights from L2 -- needs the
     // fragment-major image
-    static const int use_small = getenv("DVD_CONV_SMALLF") ? atoi(getenv("DVD_CONV_SMALLF")) : 1;
-    const bool smallf = use_small && !halo && pow2 && d->dtype == DVD_BF16 && d->wq && d->kt == 1 && d->T == 1 && !d->up2 &&
+    const bool smallf = !halo && pow2 && d->dtype == DVD_BF16 && d->wq && d->kt == 1 && d->T == 1 && !d->up2 &&
                         d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->H == d->W && (d->W == 4 || d->W == 8) &&
                         p.nsplit <= p.kchunks && M < (1ll << 24);
     const bool thin = halo && d->dtype == DVD_BF16 && d->Cout <= 64 && cdiv(M, 256) * (long long)p.nsplit >= 512;
@@ -707,31 +703,26 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
         if (wb >= 0xffffffffull) return DVD_E_SHAPE;
         p.in_bytes = inb; p.w_bytes = (unsigned)wb;
         p.maxshift = ((d->kt >> 1) * d->H + (d->kh >> 1)) * d->W + (d->kw >> 1);
-        static const int nmaj = getenv("DVD_CONV_NMAJOR") ? atoi(getenv("DVD_CONV_NMAJOR")) : 1;
-        p.nmajor = nmaj && !halo && wb > inb && wb > (4u << 20);      // weights beyond one L2 (also for the small-frame halo kernel)
+        p.nmajor = !halo && wb > inb && wb > (4u << 20);      // weights beyond one L2 (also for the small-frame halo kernel)
         // halo kernel: with several N tiles and weights well beyond one L2, a run of workgroups that shares the weight tile
         // (and streams the activations once per N tile) misses less than one that shares the footprint and cycles through
         // all the weights: 1272 -> 1355 TF/s on 786 k x 256 -> 1536 (19.7 MB of weights); neutral from 5 MiB, -1.5 % at 4.9 MB
-        static const long long nmaj_mb = getenv("DVD_CONV_NMAJOR_MB") ? atoll(getenv("DVD_CONV_NMAJOR_MB")) : 5;
-        if (nmaj && halo && p.tilesN > 1 && wb > ((size_t)nmaj_mb << 20)) p.nmajor = 1;
-        if (nmaj && halo && p.tilesN >= 6 && wb > (2u << 20)) p.nmajor = 1;      // 3.1 M x 128 -> 768 (4.9 MB, 6 N tiles): +2 %
+        if (halo && p.tilesN > 1 && wb > ((size_t)5 << 20)) p.nmajor = 1;
+        if (halo && p.tilesN >= 6 && wb > (2u << 20)) p.nmajor = 1;      // 3.1 M x 128 -> 768 (4.9 MB, 6 N tiles): +2 %
     }
     // 256-row tiles when they still give every CU work; 128-row tiles for the small recurrent convs
-    static const long long big_thr = getenv("DVD_CONV_BIGT") ? atoll(getenv("DVD_CONV_BIGT")) : 512;
+    constexpr long long big_thr = 512;          // (swept 128 / 256 / 512)
     // 1 x 1 filters are HBM-bound streams with 2-8 K steps: the 256-row tap-by-tap tile holds 433 registers = ONE workgroup per CU, the
     // 128-row tile 240 = two.  3.1 M x 128 -> 128: 665 -> 505 us, 128 -> 64: 691 -> 420, 64 -> 128: 574 -> 422; step 493.4 -> 490.9 ms
-    // (DVD_CONV_BIG1 = 1 restores the 256-row tile)
-    static const int big1 = getenv("DVD_CONV_BIG1") ? atoi(getenv("DVD_CONV_BIG1")) : 0;
     const bool one_tap = d->kt * d->kh * d->kw == 1 && !halo && !smallf;
-    const bool big = wide || (cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= big_thr && !(one_tap && !big1));   // >= 2 workgroups per CU
+    const bool big = wide || (cdiv(M, 256) * (long long)p.tilesN * p.nsplit >= big_thr && !one_tap);   // >= 2 workgroups per CU
     p.pm = 0;
     {   // pixel-major row order for the tap-by-tap kernel on small frames: the rows of a tile must share their image line
-        static const int use_pm = getenv("DVD_CONV_PIXMAJOR") ? atoi(getenv("DVD_CONV_PIXMAJOR")) : 1;
         const int bmt = (wide || big) ? 256 : 128;
         const int F = d->frames;
         const bool lines = (F % bmt == 0) || (bmt % F == 0 && d->W % (bmt / F) == 0);
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
-        if (use_pm && !halo && !smallf && pow2 && d->kt == 1 && d->T == 1 && !d->up2 && d->kh >= 3 && d->H <= 8 && lines &&
+        if (!halo && !smallf && pow2 && d->kt == 1 && d->T == 1 && !d->up2 && d->kh >= 3 && d->H <= 8 && lines &&
             (size_t)M * (size_t)(d->ldi > 3 * d->Cout ? d->ldi : 3 * d->Cout) * 4 < (1ull << 31))     // every epilogue offset from row 0 fits
             p.pm = F;
     }

@@ -242,7 +242,7 @@ __global__ void thin_out_image_kernel(const bf16_t* w, bf16_t* wt, int R) {
 
 // (internal) 1 when the request is served by conv_thin_in_kernel, given its weight image in d->wq
 int dvd_conv_thin_in_ok(const dvd_conv_desc* d) {
-    static const int use = getenv("DVD_CONV_THIN") ? atoi(getenv("DVD_CONV_THIN")) : 1;
+    constexpr int use = 1;
     if (!use || !d || d->dtype != DVD_BF16 || d->C != 8 || d->ldi != 8 || d->Cout != 64 || d->ldo < 64 || (d->ldo & 7)) return 0;
     if (d->kh != 3 || d->kw != 3 || (d->kt != 1 && d->kt != 3) || d->up2 || d->res || d->ws || d->nsplit > 1 || d->out_f32) return 0;
     if (d->act != DVD_ACT_NONE && d->act != DVD_ACT_RELU) return 0;
@@ -274,7 +274,7 @@ extern "C" int dvd_conv_thin_image(const void* w, void* wt, int kt, void* stream
 
 // (internal) 1 when the request is served by conv_thin_out_kernel, given its weight image in d->wq
 int dvd_conv_thin_out_ok(const dvd_conv_desc* d) {
-    static const int use = getenv("DVD_CONV_THIN") ? atoi(getenv("DVD_CONV_THIN")) : 1;
+    constexpr int use = 1;
     if (!use || !d || d->dtype != DVD_BF16 || d->C != 64 || d->ldi < 64 || (d->ldi & 7) || d->Cout < 1 || d->Cout > 8 || d->ldo < 8 || (d->ldo & 7)) return 0;
     if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->T != 1 || d->up2 || d->res || d->ws || d->nsplit > 1 || d->out_f32) return 0;
     if (d->act != DVD_ACT_NONE && d->act != DVD_ACT_RELU && d->act != DVD_ACT_TANH) return 0;

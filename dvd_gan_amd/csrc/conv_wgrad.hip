@@ -201,7 +201,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
                     float a = 0.f;
                     for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
                     const int co = co0 + tid * 8 + k;
-                    if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+                    if (p.wsb) p.wsb[((size_t)bz * p.tiles_co + tco) * BMc + tid * 8 + k] = a;     // partial of (slice, channel tile): wgrad_bias_reduce_kernel
+                    else if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);                  // (a single slice: one addition per channel)
                 }
             }
             __syncthreads();
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
                     float a = 0.f;
                     for (int r = 0; r < 8; ++r) a += red[(r * 32 + tid) * 4 + k];
                     const int co = co0 + tid * 4 + k;
-                    if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+                    if (p.wsb) p.wsb[((size_t)bz * p.tiles_co + tco) * BMc + tid * 4 + k] = a;
+                    else if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
                 }
             }
             __syncthreads();
@@ -682,6 +684,16 @@ __global__ __launch_bounds__(1024) void wgrad_row_bias_reduce_kernel(WgBiasRedK 
     }
 }
 
+// bias gradient of the one-tap kernel's workspace path: dbias[co] += sum over the row slices, in slice order
+__global__ void wgrad_bias_reduce_kernel(const float* wsb, float* dbias, int nslice, int tiles_co, int BMc, int Cout) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Cout) return;
+    const int tco = co / BMc, c = co - tco * BMc;
+    float a = 0.f;
+    for (int z = 0; z < nslice; ++z) a += wsb[((size_t)z * tiles_co + tco) * BMc + c];
+    dbias[co] += a;
+}
+
 // Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
 struct WgRedK { const float* ws; float* dw; int nslice, gx, gx_per_tap, tiles_ci, BMc, BNc, Cout, Cin_real; long long s_co, s_ci, s_tap; int overwrite; };
 __global__ void wgrad_reduce_kernel(WgRedK p) {
@@ -729,25 +741,21 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         if (d->Cout >= 192) ta = 4;
         else if (d->Cin_real >= 192) tb = 4;
     }
-    static const int use_row = getenv("DVD_WG_ROW") ? atoi(getenv("DVD_WG_ROW")) : 1;
-    mode = (use_row && pow2 && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) &&
+    mode = (pow2 && d->dtype == DVD_BF16 && d->kh == d->kw && (d->kw == 3 || d->kw == 5) && (!d->up2 || (d->kw == 3 && d->kt == 1)) &&
             ((d->W >= 8 && (d->H * d->W) % 32 == 0) ||
              // 4 x 4 frames (round 4): a 32-pixel step = two whole frames
              (d->W == 4 && d->H == 4 && d->kt == 1 && d->T == 1 && !d->up2 && (d->frames & 1) == 0))) ? 1 : 0;
     if (mode == 1) {   // 64 channels for thin outputs, else 256 or 128, whichever pads Cout less (256 on a tie)
         const int w4 = (d->Cout + 255) / 256 * 256, w2 = (d->Cout + 127) / 128 * 128;
-        static const int force_wm = getenv("DVD_WGR_WM") ? atoi(getenv("DVD_WGR_WM")) : 0;
         ta = d->Cout <= 64 ? 1 : (w4 <= w2 ? 4 : 2); tb = 1;
-        if (force_wm && ta > force_wm) ta = force_wm;
         // 128-channel output tile, 5 taps: take 128 input channels too (one 8-wave workgroup per CU whose halves stagger their
         // loads, like the 256-channel tile) when that pads Cin no further: 1.20 -> 1.33 PF/s on 3.1 M x 256 -> 384; with 3 taps
         // the two 4-wave workgroups per CU of the 64-channel form stay 3 % ahead
-        static const int wide = getenv("DVD_WGR_NH4") ? atoi(getenv("DVD_WGR_NH4")) : 1;
-        if (wide && ta == 2 && d->kw == 5 && !d->up2 && (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64) tb = 2;
+        if (ta == 2 && d->kw == 5 && !d->up2 && (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64) tb = 2;
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
-    { static const int xr = getenv("DVD_WG_XCD") ? atoi(getenv("DVD_WG_XCD")) : 1; p.xcd_remap = xr; }
+    p.xcd_remap = 1;
     {
         const size_t esz = d->dtype == DVD_BF16 ? 2 : 4;
         const size_t rows_in = (size_t)d->frames * d->T * p.Hin * p.Win;
@@ -760,21 +768,20 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     if (msplit < 1) {   // auto: ~16 workgroups per CU, every workgroup keeping >= 4k rows of reduction.  Swept on the
                         // full step with the workspace reduction (ms of wgrad per step): (1024,8192) 292,
                         // (1536,8192) 267, (3072,4096) 247, (4096,4096) 243, (6144,4096) 242, (8192,2048) 252
-        static const long long tgt = getenv("DVD_WG_TGT") ? atoll(getenv("DVD_WG_TGT")) : 2048;   // re-swept with whole-round grids: 4096 185.6, 2048 183.2, 1024 183.5 ms
-        static const long long minrows = getenv("DVD_WG_ROWS") ? atoll(getenv("DVD_WG_ROWS")) : 4096;
+        constexpr long long tgt = 2048;   // re-swept with whole-round grids: 4096 185.6, 2048 183.2, 1024 183.5 ms
+        constexpr long long minrows = 4096;
         // (rounds 1-3, swept with whole-round grids: 1024 187.7, 1536 185.1, 2048 190.8, 3072 192.2 ms of weight gradients.  End of round 4 -- the
         //  chain's kernels no longer leave the side stream the CUs they used to -- fewer, longer slices win on the STEP: 256 503.4 / 503.8,
         //  384 498.1 / 498.1, 512 495.6 / 495.7, 768 497.7 / 498.5, 1024 498.4 / 497.3, 1536 500.4 / 500.3, 3072 501.3 ms, one box)
-        static const long long tgt_row = getenv("DVD_WGR_TGT") ? atoll(getenv("DVD_WGR_TGT")) : 512;
+        constexpr long long tgt_row = 512;
         const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps);
         msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
         const long long cap = M / minrows > 0 ? M / minrows : 1;
         if (msplit > cap) msplit = cap;
         // whole rounds: the workgroups run `conc` at a time (register / LDS limited); a grid a few workgroups over a
         // multiple of that pays a full extra round (20 x 103 = 2060 workgroups = 8.05 rounds of 256 -> 9 rounds)
-        static const int quant = getenv("DVD_WG_QUANT") ? atoi(getenv("DVD_WG_QUANT")) : 1;
         const long long conc = 256ll * ((mode == 1 && (ta == 4 || tb == 2)) ? 1 : 2);
-        if (quant && base * msplit > conc) {
+        if (base * msplit > conc) {
             const long long rounds = (base * msplit + conc / 2) / conc;           // nearest
             long long ms2 = rounds * conc / base;
             if (ms2 >= 1 && ms2 <= cap) msplit = ms2;
@@ -799,7 +806,7 @@ extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
     if (const long long thin = dvd_wgrad_thin_ws_floats(d)) return thin;       // 3 (8) channels on one side: wgrad_thin.hip
     if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
     if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) + msplit * (long long)grid.x * (ta * 64);   // + bias partials
-    return msplit * (long long)grid.x * (ta * 64) * (tb * 64);
+    return msplit * (long long)grid.x * (ta * 64) * (tb * 64) + msplit * (long long)p.tiles_co * (ta * 64);      // + bias partials
 }
 
 extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
@@ -820,7 +827,8 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
         if (!p.ws && hipMemsetAsync(d->dw, 0, (size_t)d->Cout * d->Cin_real * ntaps * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return DVD_E_LAUNCH;                   // single slice: the kernel adds with atomics
     }
-    p.wsb = (p.ws && mode == 1) ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) : nullptr;
+    p.wsb = !p.ws ? nullptr : mode == 1 ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64)
+                                        : p.ws + msplit * (long long)grid.x * (ta * 64) * (tb * 64);
     ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
@@ -866,6 +874,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
                  p.Cin_real, p.s_co, p.s_ci, p.s_tap, overwrite};
         const long long n = (long long)grid.x * r.BMc * r.BNc;
         wgrad_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
+        if (p.dbias) wgrad_bias_reduce_kernel<<<cdiv(p.Cout, 256), 256, 0, st>>>(p.wsb, p.dbias, (int)msplit, p.tiles_co, ta * 64, p.Cout);
     }
     return launch_status();
 }

@@ -239,21 +239,19 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
     const int bk = dtype == DVD_BF16 ? 32 : 16;
     const long long nk = (long long)ntaps * ((C + bk - 1) / bk);
     const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    static const long long target_env = getenv("DVD_NS_TARGET") ? atoll(getenv("DVD_NS_TARGET")) : 0;
     // round 3 (gate math batched in the conv epilogue, tools/gru_microbench.py sweep): a 5 x 5 conv with a short K loop
     // (C = 128: 100 steps) no longer gains from a split plus gate kernel once it has 512 tiles (S = 32, h = 128:
     // 180.5 / 208.7 -> 171.0 / 196.4 us per step forward / backward); the long loops (C = 512: 400 steps) still do
     // (round 4, weights from L2: nk = 200 -- the d[u|r] conv of gru3.l2 -- is better off unsplit too: 187.6 -> 174.2 us per step)
-    const long long target = target_env ? target_env : (ntaps <= 9 || nk <= 200 ? 512 : 1024);
+    const long long target = ntaps <= 9 || nk <= 200 ? 512 : 1024;
     long long ns = (target + tiles - 1) / tiles;
     // (cap: 8 since the pixel-major tile order skips the out-of-frame filter rows of the 4 x 4 convs -- their K loops are
     //  shorter, and 16 slabs of 2 MB cost more in the gate kernels than they return: 39.1 / 39.4 -> 34.3 / 34.1 us per step)
-    static const bool cap_env = getenv("DVD_NS_CAP") != nullptr;
-    static const long long cap = cap_env ? atoll(getenv("DVD_NS_CAP")) : 8;
+    constexpr long long cap = 8;
     if (ns > cap) ns = cap;
     // (round 4, whole-frame footprint kernel: the 3 x 3 layers on 8 x 8 frames -- 18 K steps per slice at 4 -- lose more in the gate
     //  kernel's eight slabs than the fuller launch returns: 114.6 / 111.8 -> 100.6 / 102.1 us per step for gru1.l0 / l2, forward + backward)
-    if (!cap_env && ntaps <= 9 && M >= 4096 && ns > 4) ns = 4;
+    if (ntaps <= 9 && M >= 4096 && ns > 4) ns = 4;
     if (ns > nk) ns = nk;
     if (ns < 1) ns = 1;
     return (int)ns;
@@ -265,10 +263,9 @@ extern "C" int dvd_conv_pick_nsplit(int dtype, long long M, int Cout, int C, int
 // 509.2 / 536.1 (5 x 5); at 4 slices it still gains a little (S = 8, 3 x 3: 50.5 / 53.3 -> 47.6 / 50.9); at 8 the serial read of eight
 // slabs by ONE workgroup per tile costs more than the gate kernel, which spreads the same reads over the whole chip (S = 4:
 // 33.9 / 35.9 -> 37.9 / 39.4, 67.3 / 69.6 -> 72.6 / 80.3).  Fewer, longer slices so that everything combines in-launch lose as well
-// (DVD_NS_CAP = 2: the S = 4 / 8 layers 56.4 -> 70.4 ms over a pass pair).  DVD_GRU_INLAUNCH = 0 (never) ... 8 is an A/B aid.
+// (at most 2 slices everywhere: the S = 4 / 8 layers 56.4 -> 70.4 ms over a pass pair).  dvd_gru_desc.combine_max overrides the 4.
 static int inlaunch_max() {
-    static const int v = getenv("DVD_GRU_INLAUNCH") ? atoi(getenv("DVD_GRU_INLAUNCH")) : 4;
-    return v;
+    return 4;
 }
 
 // floats of dvd_gru_desc.ws: nsplit slabs of whole output tiles (up to 256 rows x 256 columns) for the widest of the three
@@ -449,8 +446,6 @@ int stack_kind(const dvd_gru_stack_desc* s) {
     if (a.H != 8) return -1;
     long long t256 = 0;                              // tiles of the U group on 256-row tiles
     for (int l = 0; l < s->n_layers; ++l) t256 += (long long)cdiv(a.B, 4) * cdiv(2 * s->layer[l].hidden, 128);
-    static const int k8 = getenv("DVD_STACK_K8") ? atoi(getenv("DVD_STACK_K8")) : 0;
-    if (k8) return k8;
     return t256 >= 256 ? 2 : 3;
 }
 long long kind_mtiles(int kind, int B, int H, int W) {
@@ -497,12 +492,10 @@ int run_group(const dvd_gru_stack_desc* s, int kind, Member* m, GruEpi* g, int n
     if (n == 0) return DVD_OK;
     long long total = 0;
     for (int i = 0; i < n; ++i) total += m[i].tiles;
-    static const long long tgt_env = getenv("DVD_STACK_TGT") ? atoll(getenv("DVD_STACK_TGT")) : 0;       // (sweep aids)
-    static const long long cap_env = getenv("DVD_STACK_NSMAX") ? atoll(getenv("DVD_STACK_NSMAX")) : 0;
     // measured (tools/gru_microbench.py stack, B = 64): (target, cap) = (768, 4) 5.46 / 6.99 ms forward / backward on 4 x 4 frames,
     // (768, 8) 5.66 / 6.16; 8 x 8 frames: (768, 4) 14.86 / 15.09, (768, 8) 14.93 / 15.95, (384, 4) 14.46 / 16.53, (1536, *) slower
-    const long long cap = cap_env ? cap_env : (kind == 4 && backward) ? 8 : 4;
-    const long long target = tgt_env ? tgt_env : (kind == 0 || kind == 2) ? 512 : 768;
+    const long long cap = (kind == 4 && backward) ? 8 : 4;
+    const long long target = (kind == 0 || kind == 2) ? 512 : 768;
     long long want = (target + total - 1) / total;
     if (want > cap) want = cap;
     long long cursor = 0;
@@ -577,8 +570,12 @@ int stack_forward(const dvd_gru_stack_desc* s, void* stream, bool dry, long long
                 mem[n].gate = 1;
                 ++n;
             }
-            if (phase == 1)
-                for (int l = 1; l < L; ++l) {                     // x-part of layer l for step k - 2 l + 1
+            // bit l: the x-part of layer l rides in the U group instead of the O group (both are behind its producer).  Measured
+            // (tools/gru_microbench.py stack): no difference beyond noise except on 8 x 8 frames, where the top layer's x-part in the
+            // U group balances the two launches of a pair (14.63 -> 13.93 ms forward, 15.77 -> 14.76 backward)
+            const int x_in_u = s->layer[0].H == 8 ? 4 : 0;
+            for (int l = 1; l < L; ++l)
+                if (phase == (((x_in_u >> l) & 1) ? 0 : 1)) {     // x-part of layer l for step k - 2 l + 1
                     const dvd_gru_desc& d = s->layer[l];
                     const dvd_gru_desc& b = s->layer[l - 1];
                     const int t = k - 2 * l + 1;
@@ -602,6 +599,7 @@ int stack_backward(const dvd_gru_stack_desc* s, void* stream, bool dry, long lon
     const long long M = (long long)s->layer[0].B * s->layer[0].H * s->layer[0].W;
     const size_t esz = 2;
     using T_ = bf16_t;
+    const int dx_in_a = s->layer[0].H == 8 ? 4 : 0;       // bit l: layer l's x-part backward-data rides in the NEXT pair's A group (see x_in_u)
     if (!dry)
         for (int l = 0; l < L; ++l)
             if (hipMemsetAsync(s->layer[l].carry, 0, (size_t)M * s->layer[l].hidden * sizeof(float), S_) != hipSuccess) return DVD_E_LAUNCH;
@@ -619,6 +617,19 @@ int stack_backward(const dvd_gru_stack_desc* s, void* stream, bool dry, long lon
             for (int l = L - 1; l >= 0; --l) {
                 const dvd_gru_desc& d = s->layer[l];
                 const int t = T - 1 - (k - 2 * (L - 1 - l)), h = d.hidden;
+                if (phase == 0 && l > 0 && ((dx_in_a >> l) & 1) && t >= -1 && t + 1 < T) {     // x-part backward-data of the step finished in the previous pair
+                    const int ci = s->cin[l];
+                    char* dgp = (char*)d.dg + (size_t)(t + 1) * M * 3 * h * esz;
+                    epi[n] = GruEpi{};
+                    member_conv(mem[n], d, dgp, 3 * h, 3 * h, s->wdx[l], s->wdx_q[l], ci, kind);
+                    mem[n].d.out = (char*)s->dh_mid[l] + (size_t)(t + 1) * M * ci * esz;
+                    mem[n].d.ldo = ci;
+                    if (s->layer[l - 1].dh_out) {
+                        mem[n].d.res = (const char*)s->layer[l - 1].dh_out + (size_t)(t + 1) * M * ci * esz;
+                        mem[n].d.ldres = ci;
+                    }
+                    ++n;
+                }
                 if (t < 0 || t >= T) continue;
                 const size_t step = (size_t)M * h * esz;
                 const char* hprev = t > 0 ? (const char*)d.h_all + (t - 1) * step : (const char*)d.h0;
@@ -660,7 +671,7 @@ int stack_backward(const dvd_gru_stack_desc* s, void* stream, bool dry, long lon
                         mem[n].d.out = d.carry; mem[n].gate = 1;
                         ++n;
                     }
-                    if (l > 0) {                                  // x-part backward-data: gradient reaching layer l-1's state of step t
+                    if (l > 0 && !((dx_in_a >> l) & 1)) {         // x-part backward-data: gradient reaching layer l-1's state of step t
                         const int ci = s->cin[l];
                         epi[n] = GruEpi{};
                         member_conv(mem[n], d, dg, 3 * h, 3 * h, s->wdx[l], s->wdx_q[l], ci, kind);

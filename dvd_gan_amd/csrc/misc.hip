@@ -118,24 +118,27 @@ __global__ __launch_bounds__(256) void sn_pack_batched_kernel(const dvd_sn_item*
     if (it.dtype == DVD_BF16) sn_pack_one<bf16_t>(it, i); else sn_pack_one<float>(it, i);
 }
 
-// dot += sum G*W
-__global__ void sn_dot_kernel(const float* G, const float* W, long long n, float* dot) {
+// partial[block] = this block's share of sum G*W (no atomics: sn_grad_kernel adds the partials in a fixed order)
+__global__ void sn_dot_kernel(const float* G, const float* W, long long n, float* partial) {
     __shared__ float sh[32];
     float a = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         a += G[i] * W[i];
     a = block_sum(a, sh);
-    if (threadIdx.x == 0) atomicAdd(dot, a);
+    if (threadIdx.x == 0) partial[blockIdx.x] = a;
 }
-// W_sn = W/sigma, sigma = u.(W v)  =>  dL/dW = G/sigma - (sum G*W)/sigma^2 * u v^T
-__global__ void sn_grad_kernel(const float* G, const float* u, const float* v, const float* sigma, const float* dot,
-                               int h, int w, float* dW) {
+// W_sn = W/sigma, sigma = u.(W v)  =>  dL/dW = G/sigma - (sum G*W)/sigma^2 * u v^T        (npart <= 512 partials of sum G*W)
+__global__ __launch_bounds__(256) void sn_grad_kernel(const float* G, const float* u, const float* v, const float* sigma, const float* partial,
+                                                      int npart, int h, int w, float* dW) {
+    __shared__ float sh[32];
+    const int t = threadIdx.x;
+    const float dot = block_sum((t < npart ? partial[t] : 0.f) + (t + 256 < npart ? partial[t + 256] : 0.f), sh);   // same order in every block
     const long long n = (long long)h * w;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r = (int)(i / w), c = (int)(i - (long long)r * w);
     const float s = *sigma;
-    dW[i] += G[i] / s - (*dot) / (s * s) * u[r] * v[c];
+    dW[i] += G[i] / s - dot / (s * s) * u[r] * v[c];
 }
 // out = W / sigma
 __global__ void sn_scale_kernel(const float* W, const float* sigma, float* out, long long n) {
@@ -189,12 +192,19 @@ __global__ void linear_bwd_w_kernel(const float* dout, const float* in, float* d
     dW[i] += a;
     if (dbias && k == 0) dbias[j] += s;
 }
-// dW[idx[i]][:] += dout[i][:]
+// dW[idx[i]][:] += dout[i][:].  The rows that share an index are added by the thread of their FIRST occurrence, in row order
+// (fp32 atomics per row gave a run-to-run order whenever a class came up three times in the batch).
 __global__ void embedding_bwd_kernel(const float* dout, const int* idx, float* dW, long long n, int D) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * D) return;
     const long long r = i / D;
-    atomicAdd(dW + (size_t)idx[r] * D + (i - r * D), dout[i]);
+    const int c = (int)(i - r * D), row = idx[r];
+    for (long long q = 0; q < r; ++q)
+        if (idx[q] == row) return;
+    float a = 0.f;
+    for (long long q = r; q < n; ++q)
+        if (idx[q] == row) a += dout[q * D + c];
+    dW[(size_t)row * D + c] += a;
 }
 
 // ----------------------------------------------------------------------------- projection head
@@ -247,7 +257,8 @@ __global__ void proj_head_fwd_kernel(const float* hsum, const float* wl, const f
     a = wave_sum(a);
     if (lane == 0) out[f] = a + bias[0];
 }
-// dh[f][c] = dout[f] * (wl[c]/sl + emb[cls][c]/se);  G_lin[c] += dout[f] h[f][c];  G_emb[cls][c] += dout[f] h[f][c]
+// dh[f][c] = dout[f] * (wl[c]/sl + emb[cls][c]/se);  G_lin[c] += dout[f] h[f][c];  G_emb[cls][c] += dout[f] h[f][c].
+// All three sums run in frame order inside ONE thread each (G_emb: the thread of the first frame of a class), no atomics.
 __global__ void proj_head_bwd_kernel(const float* dout, const float* hsum, const float* wl, const float* sl,
                                      const float* emb, const float* se, const int* cls, float* dh, float* g_lin,
                                      float* g_emb, float* g_bias, long long F, int C) {
@@ -256,14 +267,22 @@ __global__ void proj_head_bwd_kernel(const float* dout, const float* hsum, const
     const long long f = i / C;
     const int c = (int)(i - f * C);
     const float d = dout[f];
-    const size_t e = (size_t)cls[f] * C + c;
+    const int k = cls[f];
+    const size_t e = (size_t)k * C + c;
     dh[i] = d * (wl[c] / *sl + emb[e] / *se);
-    if (g_lin) {
-        const float t = d * hsum[i];
-        atomicAdd(g_lin + c, t);
-        atomicAdd(g_emb + e, t);
-        if (c == 0) atomicAdd(g_bias, d);
+    if (!g_lin) return;
+    if (f == 0) {                                   // column c of the linear weight; the bias rides with column 0
+        float a = 0.f, b = 0.f;
+        for (long long q = 0; q < F; ++q) { a += dout[q] * hsum[q * C + c]; b += dout[q]; }
+        g_lin[c] += a;
+        if (c == 0) *g_bias += b;
     }
+    for (long long q = 0; q < f; ++q)
+        if (cls[q] == k) return;
+    float a = 0.f;
+    for (long long q = f; q < F; ++q)
+        if (cls[q] == k) a += dout[q] * hsum[q * C + c];
+    g_emb[e] += a;
 }
 
 // ----------------------------------------------------------------------------- adversarial loss
@@ -348,11 +367,10 @@ extern "C" int dvd_sn_backward(const float* G, const float* W, const float* u, c
                                int h, int w, float* dW, float* scratch, void* stream) {
     if (!G || !W || !u || !v || !sigma || !dW || !scratch || h <= 0 || w <= 0) return DVD_E_ARG;
     const long long n = (long long)h * w;
-    if (hipMemsetAsync(scratch, 0, sizeof(float), S_) != hipSuccess) return DVD_E_LAUNCH;
     unsigned g = cdiv(n, 256 * 8);
-    if (g > 512) g = 512;
+    if (g > DVD_SN_SCRATCH) g = DVD_SN_SCRATCH;
     sn_dot_kernel<<<g, 256, 0, S_>>>(G, W, n, scratch);
-    sn_grad_kernel<<<cdiv(n, 256), 256, 0, S_>>>(G, u, v, sigma, scratch, h, w, dW);
+    sn_grad_kernel<<<cdiv(n, 256), 256, 0, S_>>>(G, u, v, sigma, scratch, (int)g, h, w, dW);
     return launch_status();
 }
 extern "C" int dvd_sn_scale(const float* W, const float* sigma, float* out, long long n, void* stream) {

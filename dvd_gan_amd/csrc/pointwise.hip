@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void cbn_apply_kernel(const T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const T* g, const T* x, int P, int C,
                                                              int ld, const float* mean, const float* rstd, const float* gb,
-                                                             const int* samp, float* dgb, int relu, int chunk) {
+                                                             const int* samp, float* dgb, int relu, int chunk, float* part) {
     __shared__ float red[256][17];
     const int cg = (C + 7) / 8, nj = 256 / cg;
     const int gi = threadIdx.x % cg, j = threadIdx.x / cg;
@@ -185,13 +185,29 @@ __global__ __launch_bounds__(256) void cbn_bwd_reduce_kernel(const T* g, const T
         for (int jj = 1; jj < nj; ++jj)
 #pragma unroll
             for (int k = 0; k < 8; ++k) { dg[k] += red[jj * cg + gi][k]; db[k] += red[jj * cg + gi][8 + k]; }
-        float* o = dgb + (size_t)samp[frame] * 2 * C;
+        // with a workspace: this block's partial sums, gathered per condition row in frame order by cbn_dgb_gather_kernel
+        float* o = part ? part + ((size_t)frame * gridDim.y + blockIdx.y) * 2 * C : dgb + (size_t)samp[frame] * 2 * C;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int c = gi * 8 + k;
-            if (c < C) { atomicAdd(o + c, dg[k]); atomicAdd(o + C + c, db[k]); }
+            if (c < C) {
+                if (part) { o[c] = dg[k]; o[C + c] = db[k]; }
+                else { atomicAdd(o + c, dg[k]); atomicAdd(o + C + c, db[k]); }
+            }
         }
     }
+}
+
+// dgb[s][:] += sum over the frames conditioned on row s (in frame order) and their pixel chunks of the partial sums
+__global__ __launch_bounds__(256) void cbn_dgb_gather_kernel(const float* part, const int* samp, long long frames, int nchunk, int C2, float* dgb) {
+    const int s = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C2) return;
+    float a = 0.f;
+    for (long long f = 0; f < frames; ++f) {
+        if (samp[f] != s) continue;                    // (uniform over the block)
+        for (int k = 0; k < nchunk; ++k) a += part[((size_t)f * nchunk + k) * C2 + c];
+    }
+    dgb[(size_t)s * C2 + c] += a;
 }
 
 // s12[c] = sum_s gb[s][c] * dgb[s][C+c]   (= sum dxhat),  s12[C+c] = sum_s gb[s][c] * dgb[s][c]  (= sum dxhat*xhat)
@@ -502,7 +518,7 @@ extern "C" int dvd_bn_stats(int dtype, const void* x, long long rows, int C, int
     // every block ends with 2C fp64 atomics: 1024 blocks while that stays <= 256 k atomics per launch (3072 x 64 x 64 x 64: 459 us with
     // 512 blocks on one copy of the sums, 418 on 16 copies, 296 with 1024 blocks = 5.4 TB/s), 512 blocks for wider tensors
     // (C = 256 / 512: 112 / 63 us against 123 / 80 with 1024); 64 copies of the sums: no further gain
-    static const unsigned forced = getenv("DVD_BN_GRID") ? (unsigned)atoi(getenv("DVD_BN_GRID")) : 0u;
+    constexpr unsigned forced = 0u;
     const unsigned cap = forced ? forced : (C <= 128 ? 1024u : 512u);
     if (grid > cap) grid = cap;
     BY_DTYPE(dtype, bn_stats_kernel<T><<<grid, 256, 0, S_>>>((const T*)x, rows, C, ld, sums));
@@ -536,7 +552,7 @@ extern "C" int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames
 //   apply : dx = rstd * (g*gamma_s - s12[c]/rows_total - xhat * s12[C+c]/rows_total)
 extern "C" int dvd_cbn_backward_reduce(int dtype, const void* g, const void* a, const void* x, long long frames, int P, int C,
                                        int ld, const float* mean, const float* rstd, const float* gb, const int* samp, int B,
-                                       float* dgb, float* s12, int relu, void* stream) {
+                                       float* dgb, float* s12, int relu, float* part, void* stream) {
     (void)a;          // the ReLU mask is re-evaluated from x (cbn_affine): the stored activation is not read
     if (!g || !x || !mean || !rstd || !gb || !samp || !dgb || !s12) return DVD_E_ARG;
     if (frames <= 0 || P <= 0 || B <= 0) return DVD_E_ARG;
@@ -544,9 +560,15 @@ extern "C" int dvd_cbn_backward_reduce(int dtype, const void* g, const void* a, 
     const int chunk = 2048;
     dim3 grid((unsigned)frames, cdiv(P, chunk));
     BY_DTYPE(dtype, cbn_bwd_reduce_kernel<T><<<grid, 256, 0, S_>>>((const T*)g, (const T*)x, P, C, ld,
-                                                                   mean, rstd, gb, samp, dgb, relu, chunk));
+                                                                   mean, rstd, gb, samp, dgb, relu, chunk, part));
+    if (part) cbn_dgb_gather_kernel<<<dim3((unsigned)B, cdiv(2 * C, 256)), 256, 0, S_>>>(part, samp, frames, (int)grid.y, 2 * C, dgb);
     cbn_bwd_sums_kernel<<<cdiv(C, 128), 128, 0, S_>>>(gb, dgb, B, C, s12);
     return launch_status();
+}
+
+extern "C" long long dvd_cbn_backward_ws_floats(long long frames, int P, int C) {
+    if (frames <= 0 || P <= 0 || C <= 0) return 0;
+    return frames * cdiv(P, 2048) * 2 * C;            // (2048 = the pixel chunk of dvd_cbn_backward_reduce)
 }
 
 extern "C" int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames,
@@ -566,9 +588,9 @@ extern "C" int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, c
 
 extern "C" int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames,
                                 int P, int C, int ld, const float* mean, const float* rstd, const float* gb,
-                                const int* samp, int B, float* dgb, float* s12, int relu, void* stream) {
+                                const int* samp, int B, float* dgb, float* s12, int relu, float* part, void* stream) {
     if (!dx) return DVD_E_ARG;
-    const int rc = dvd_cbn_backward_reduce(dtype, g, a, x, frames, P, C, ld, mean, rstd, gb, samp, B, dgb, s12, relu, stream);
+    const int rc = dvd_cbn_backward_reduce(dtype, g, a, x, frames, P, C, ld, mean, rstd, gb, samp, B, dgb, s12, relu, part, stream);
     if (rc != DVD_OK) return rc;
     return dvd_cbn_backward_apply(dtype, g, a, x, dx, frames, P, C, ld, mean, rstd, gb, samp, s12, frames * P, relu, stream);
 }

@@ -173,7 +173,7 @@ __global__ void thin_reduce2_kernel(ThinRedK p) {
 struct ThinPlan { bool ok; bool thin_is_ci; int G, NU, per; long long lines; };
 ThinPlan thin_plan(const dvd_wgrad_desc* d) {
     ThinPlan q = {};
-    static const int use = getenv("DVD_WG_THIN") ? atoi(getenv("DVD_WG_THIN")) : 1;
+    constexpr int use = 1;
     if (!use || !d || d->dtype != DVD_BF16 || d->up2 || d->kh != 3 || d->kw != 3 || (d->kt != 1 && d->kt != 3)) return q;
     if (d->W < 16 || d->W > 64 || (d->W & 15) || d->H < 1 || d->T < 1 || d->frames < 1) return q;
     if (d->msplit > 1) return q;                            // a caller that asks for a specific row split gets the general kernels

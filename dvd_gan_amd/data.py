@@ -46,8 +46,10 @@ def make_dataset(root_path, annotation_path, subset, n_samples_for_each_video=1,
             continue
         if n_samples_for_each_video == 1:
             windows = [(1, total + 1)]
-        else:                                                   # windows spread evenly over the video, at least one frame apart
-            stride = max(1, math.ceil((total - 1 - sample_duration) / (n_samples_for_each_video - 1)))
+        else:                                                   # windows spread evenly over the video, at least one frame apart;
+            # n_samples_for_each_video < 1: back-to-back windows (ucf101.py:124-129: step = sample_duration)
+            stride = (max(1, math.ceil((total - 1 - sample_duration) / (n_samples_for_each_video - 1)))
+                      if n_samples_for_each_video > 1 else sample_duration)
             windows = [(first, min(total + 1, first + sample_duration)) for first in range(1, total, stride)]
         for lo, hi in windows:
             records.append({"video": folder, "segment": [1, total], "n_frames": total, "video_id": vid,

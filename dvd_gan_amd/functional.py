@@ -24,7 +24,7 @@ from . import lib as L
 # The stream that ran backward() must wait for the side stream before the gradients are read.  That join is AUTOMATIC:
 # the first side-stream launch of a backward pass queues `join_side` as a final callback of the autograd engine, so it
 # runs when that backward() returns -- whoever called it (the Trainer, a drop-in loop with a stock optimizer and
-# zero_grad(set_to_none=False), gradient accumulation, a tool that drives tr.G directly).  The Trainer additionally joins
+# zero_grad(set_to_none=False), gradient accumulation, a tool that drives tr.G directly); it is queued once per backward().  The Trainer additionally joins
 # early where a gradient bucket is handed to the exchange.  Parameters without a persistent .grad (stock optimizers with
 # zero_grad(set_to_none=True), module tests) take the autograd route unchanged.
 import os as _os
@@ -67,13 +67,20 @@ def join_side():
 
 
 def _queue_join():
-    """Called from inside a backward pass: make the running backward() end with join_side().  The callback is queued on EVERY
-    side-stream launch -- the engine runs final callbacks once per backward() and DROPS them when a backward raises, so a
-    process-wide "already queued" flag would survive a failed backward (an OOM that is caught and retried, a user hook error)
-    and silently disable the join for the rest of the process; join_side() is idempotent and costs one event wait."""
+    """Called from inside a backward pass: make the running backward() end with join_side().  Queued ONCE per backward(): the
+    autograd engine numbers its graph tasks, and the id of the task that last queued the callback is remembered -- a backward
+    that raised (the engine drops its callbacks) cannot disable the join of the next one, which runs under a new id.  (The
+    first form queued the callback on every side-stream launch: hundreds of event record / wait pairs at the end of every
+    backward pass.)"""
+    task = torch._C._current_graph_task_id()
+    if task < 0:                  # not inside a backward pass (a Function.backward driven by hand): the caller joins
+        return
+    if _SIDE.get("task") == task:
+        return
     try:
         torch.autograd.Variable._execution_engine.queue_callback(join_side)
-    except RuntimeError:          # not inside a backward pass (a Function.backward driven by hand): the caller joins
+        _SIDE["task"] = task
+    except RuntimeError:
         pass
 
 
@@ -228,6 +235,10 @@ class Conv(Function):
                 if ctx.slot is not None:                  # the other branch's gradient of the same x: summed in the epilogue
                     partner, ctx.slot.dx = ctx.slot.dx, None
                     assert not spec.relu_in
+                    if partner is None:
+                        raise RuntimeError("GradSlot: the main branch of this residual block has not left its input gradient -- its "
+                                           "backward node did not run before the shortcut's (graph pruned or re-entered?); the sum "
+                                           "d/dx would silently lose a term")
                 dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None, res=partner,
                                     wq=lambda: pk.fragment_major("wd"))
         wp, bp = ctx.params
@@ -673,7 +684,8 @@ ATTN_MFMA = _os.environ.get("DVD_ATTN_MFMA", "1") != "0"      # A/B aid: 0 = the
 
 class SelfAttention2d(Function):
     """y = gamma * softmax(q^T k) v + x      Discriminators.py:100-119; qkv from one fused 1x1 conv.
-    bf16 storage at the discriminators' widths (16 query channels, 32 / 64 / 128 value channels, <= 256 tokens per frame) runs
+    bf16 storage at the discriminators' widths (16 query channels, 128 value channels, any token count that is a multiple of 32 up to
+    4096 per frame -- dvd_attention_mfma_ok has the exact rule) runs
     on the matrix cores and keeps one number per query (dvd_attention_mfma_*); everything else runs the fp32 kernels, which keep
     the N x N map for the backward pass."""
 

@@ -147,7 +147,6 @@ class Generator(nn.Module):
                 self.self_attn = SelfAttention(c8, compute_dtype)
             if sep_attn:
                 self.sep_attn = SeparableAttn(c4, compute_dtype)
-        self._nbt_flat = None                       # the 16 `bn.num_batches_tracked` counters as views of ONE tensor (see _count_batches)
         self.dp_global = False                      # data-parallel "global" mode: conditions gathered over the ranks
         self.dp_hooks = False                       # data-parallel trainer sets it: stage-boundary gradient hooks
         self.grad_ready_hook = None                 # callable(first finished module index), armed around backward
@@ -159,32 +158,28 @@ class Generator(nn.Module):
         [B, hidden_l, S, S] fp32 (None entries = zeros).  They take the place of the `hidden=None` the reference passes at
         the first frame (Generator.py:91,96 -> ConvGRU.forward(x, hidden), ConvGRU.py:104-118) and receive gradients."""
         sn = prefetch_spectral_norm(self, self.compute_dtype)    # SN + weight packing of all layers on the side stream
+        counted = self._count_batches() if self.training else []
+        for m in counted:
+            m.count_batches = False
         try:
             return self._forward(x, class_id, hidden)
         finally:
+            for m in counted:
+                m.count_batches = True
             clear_spectral_norm(sn)
 
-    def _count_batches(self, dev):
+    def _count_batches(self):
         """BatchNorm2d's `num_batches_tracked += 1` of all sixteen conditional batch norms (Normalization.py:72, train mode) as ONE
-        launch: the counters are re-homed as 0-d views of one int64 tensor (state_dict keys and values unchanged; `.to()` / a
-        deep copy replace the buffers, which is noticed by address and repaired here)."""
+        multi-tensor launch.  The counters stay the modules' own buffers (nothing is re-homed: shadow copies, EMA code and
+        `.to()` keep seeing the tensors they hold); the layers' own increment is switched off only for the duration of this
+        forward, so a ConditionalNorm / GResBlock driven on its own afterwards counts for itself again."""
         mods = [m for m in self.modules() if isinstance(m, ConditionalNorm)]
-        flat = self._nbt_flat
-        ok = flat is not None and flat.device == dev and flat.numel() == len(mods) and all(
-            m.bn.num_batches_tracked.data_ptr() == flat[i].data_ptr() and not m.count_batches for i, m in enumerate(mods))
-        if not ok:
-            flat = torch.stack([m.bn.num_batches_tracked.detach().reshape(()).to(dev) for m in mods]).clone()
-            for i, m in enumerate(mods):
-                m.bn._buffers["num_batches_tracked"] = flat[i]
-                m.count_batches = False
-            self._nbt_flat = flat
-        flat += 1
+        torch._foreach_add_([m.bn.num_batches_tracked for m in mods], 1)
+        return mods
 
     def _forward(self, x, class_id, hidden=None):
         B, T = x.shape[0], self.n_frames
         dev = x.device
-        if self.training:
-            self._count_batches(dev)
         class_emb = Fn.Embedding.apply(self.embedding.weight, class_id.to(torch.int32))
         zc = torch.cat([x, class_emb], 1)
         y = Fn.LinearF32.apply(zc, self.affine_transfrom.weight, self.affine_transfrom.bias)

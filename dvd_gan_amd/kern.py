@@ -286,14 +286,15 @@ def cbn_backward(g, a, x, C_real, mean, rstd, gb, samp, relu, replicas=None):
     B = gb.shape[0]
     dgb = torch.zeros_like(gb)
     s12 = torch.empty(2 * C_real, dtype=torch.float32, device=x.device)
+    part = torch.empty(L.lib().dvd_cbn_backward_ws_floats(_ll(frames), P, C_real), dtype=torch.float32, device=x.device)   # fixed-order dgb
     if replicas is None:
         L.check(L.lib().dvd_cbn_backward(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
                                          x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb),
-                                         L.ptr(s12), int(relu), L.stream()))
+                                         L.ptr(s12), int(relu), L.ptr(part), L.stream()))
         return dx, dgb
     L.check(L.lib().dvd_cbn_backward_reduce(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), _ll(frames), P, C_real, x.shape[-1],
                                             L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb), L.ptr(s12),
-                                            int(relu), L.stream()))
+                                            int(relu), L.ptr(part), L.stream()))
     replicas[1](s12)
     L.check(L.lib().dvd_cbn_backward_apply(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
                                            x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), L.ptr(s12),
@@ -393,7 +394,7 @@ def sn_power_iter(w_bar, u, v, sigma=None):
 def sn_backward(G, w_bar, u, v, sigma, out=None):
     """dL/dW_bar from G = dL/d(W_bar / sigma); `out`: fp32 buffer the result is ADDED to (default: a fresh zero tensor)."""
     dW = torch.zeros_like(w_bar) if out is None else out
-    scratch = torch.empty(1, dtype=torch.float32, device=w_bar.device)
+    scratch = torch.empty(L.SN_SCRATCH, dtype=torch.float32, device=w_bar.device)
     h = w_bar.shape[0]
     L.check(L.lib().dvd_sn_backward(L.ptr(G), L.ptr(w_bar), L.ptr(u), L.ptr(v), L.ptr(sigma), h, w_bar.numel() // h,
                                     L.ptr(dW), L.ptr(scratch), L.stream()))

@@ -48,6 +48,7 @@ def lib():
         _lib.dvd_conv_thin_image_bytes.restype = C.c_longlong
         _lib.dvd_conv_thin_out_image_bytes.restype = C.c_longlong
         _lib.dvd_convgru_stack_ws_floats.restype = C.c_longlong
+        _lib.dvd_cbn_backward_ws_floats.restype = C.c_longlong
         if _lib.dvd_abi_version() != ABI_VERSION:
             raise RuntimeError("libdvdgan_hip.so ABI version mismatch: rebuild it")
         # layout handshake: every descriptor mirror below must have the size the library was compiled with
@@ -62,10 +63,12 @@ def lib():
 
 ABI_VERSION = 11
 BN_NREP = 16            # DVD_BN_NREP of include/dvdgan_hip.h
+SN_SCRATCH = 512        # DVD_SN_SCRATCH
 
 
 def check(code):
     if code != 0:
+        reset_gru_tickets()           # a failed / aborted launch may have left split-K tickets behind: the next one must start from zero
         raise RuntimeError(f"libdvdgan_hip: {lib().dvd_strerror(code).decode()} (code {code})")
 
 
@@ -89,6 +92,19 @@ def stream():
 
 
 _tickets = {}
+
+
+def reset_gru_tickets(current_stream_only=False):
+    """Zero the cached ticket buffers (all of them, or the current stream's; the fill runs on the current stream).  The in-launch split-K combine assumes zeroed counters and
+    restores them itself, but only when a launch runs to completion: called after any failed library call and once per training
+    step (one 32 KB fill), so a faulted or killed launch cannot make later ConvGRU passes skip or mis-time their gate epilogues."""
+    for (index, st), t in list(_tickets.items()):
+        try:
+            if current_stream_only and st != torch.cuda.current_stream(t.device).cuda_stream:
+                continue
+            t.zero_()
+        except Exception:
+            pass
 
 
 def gru_tickets(device):

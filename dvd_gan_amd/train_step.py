@@ -16,6 +16,7 @@ import time
 import torch
 
 from . import functional as Fn
+from . import lib as L
 from . import dist as D
 from .dist import GradExchange
 from .disc_nets import SpatialDiscriminator, TemporalDiscriminator
@@ -252,6 +253,7 @@ class Trainer(object):
         return out
 
     def _train_step(self, real_videos, real_labels, draws=None, hidden=None):
+        L.reset_gru_tickets(current_stream_only=True)         # split-K tickets start every step from zero (lib.reset_gru_tickets)
         real_videos = to_device_async(real_videos, self.device).permute(0, 2, 1, 3, 4).contiguous()
         real_labels = to_device_async(self._check_labels(real_labels), self.device)
         T, k = self.n_frames, self.k_sample

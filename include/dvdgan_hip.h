@@ -281,14 +281,17 @@ int dvd_cbn_apply(int dtype, const void* x, void* y, long long frames, int P, in
  * same fused multiply-add the forward used (two HBM passes fewer than reading it). */
 int dvd_cbn_backward(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames, int P,
                      int C, int ld, const float* mean, const float* rstd, const float* gb, const int* samp, int B,
-                     float* dgb, float* s12, int relu, void* stream);
+                     float* dgb, float* s12, int relu, float* part, void* stream);
+/* `part`: optional workspace of dvd_cbn_backward_ws_floats() floats -- the per-(frame, pixel chunk) partial sums of dgb are written
+ * there and added per condition row in frame order (run-to-run reproducible); NULL = fp32 atomics straight into dgb. */
+long long dvd_cbn_backward_ws_floats(long long frames, int P, int C);
 /* The same in two stages, for cross-replica batch norm (the reference leaves it as a TODO, Generator.py:57; autograd of
  * F.batch_norm over a global batch): `reduce` accumulates dgb and writes the two per-channel sums s12[2C]; the caller
  * all-reduces s12 over the replicas; `apply` produces dx with rows_total = frames * P summed over the replicas.
  * dvd_cbn_backward == reduce + apply with rows_total = frames * P. */
 int dvd_cbn_backward_reduce(int dtype, const void* g, const void* a, const void* x, long long frames, int P, int C, int ld,
                             const float* mean, const float* rstd, const float* gb, const int* samp, int B, float* dgb,
-                            float* s12, int relu, void* stream);
+                            float* s12, int relu, float* part, void* stream);
 int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, const void* x, void* dx, long long frames, int P, int C,
                            int ld, const float* mean, const float* rstd, const float* gb, const int* samp, const float* s12,
                            long long rows_total, int relu, void* stream);
@@ -318,8 +321,9 @@ int dvd_row_copy(const float* src, float* dst, const int* idx, long long nrows, 
  *   dW_bar += G/sigma - (sum G*W_bar)/sigma^2 * u v^T        (u, v: CURRENT buffers, quirk 7)
  * ---------------------------------------------------------------------------------------- */
 int dvd_sn_power_iter(const float* W, int h, int w, float* u, float* v, float* sigma, void* stream);
+#define DVD_SN_SCRATCH 512   /* floats of dvd_sn_backward's `scratch`: per-block partial sums of sum G*W_bar, added in a fixed order (no atomics) */
 int dvd_sn_backward(const float* G, const float* W, const float* u, const float* v, const float* sigma, int h, int w,
-                    float* dW, float* scratch /*1 float*/, void* stream);
+                    float* dW, float* scratch /*DVD_SN_SCRATCH floats*/, void* stream);
 int dvd_sn_scale(const float* W, const float* sigma, float* out, long long n, void* stream);
 /* The power iterations AND the sigma-normalised MFMA weight images of ALL spectrally normalised convolutions of a network in
  * four launches (the reference runs Normalization.py:19-31 inside every layer's forward): W^T u for every matrix,

@@ -135,6 +135,31 @@ def test_convgru_stack_bptt(golden, dtype):
     check_param_grads(gru, sub(g, "grad"), gt)
 
 
+def test_gresblock_partial_autograd_leaves_no_stale_gradient(golden):
+    """functional.GradSlot hands the main branch's input gradient to the shortcut conv's backward.  torch.autograd.grad restricted
+    to the conditional-norm parameters prunes the shortcut's node: nothing may leak into a later full backward, whose input
+    gradient must equal the one of an undisturbed run."""
+    from dvd_gan_amd.gen_net import GResBlock
+    g = sub(golden("f3_gresblock"), "up1")
+    samp = torch.arange(6, dtype=torch.int32, device=DEV)
+
+    def run(partial_first):
+        blk = load(GResBlock(8, 8, 12, 1), sub(g, "sd0")).train()     # (a forward advances the spectral-norm state: fresh block per run)
+        x = t(g["in.x"], True)
+        cond = t(g["in.cond"])
+        y = blk.run(cl(x, torch.float32), cond, samp)
+        if partial_first:
+            gw, = torch.autograd.grad(y.float().sum(), [blk.CBNorm1.embed.weight], retain_graph=True)
+            assert torch.isfinite(gw).all()
+        for p in blk.parameters():
+            p.grad = None
+        ncl(y, 8).backward(t(g["in.gy"]))
+        return x.grad.clone()
+    a, b = run(False), run(True)
+    assert rel(a, g["grad.x"]) < 2e-4
+    assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------ F5
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("tag,C", [("n16", 16), ("n64", 8)])

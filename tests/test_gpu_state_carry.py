@@ -176,19 +176,18 @@ def test_state_carry_step_bf16(golden):
             num[f"cos.{s}.G.{kk}"] = cosine(snaps["G"][kk], wsn["G"][kk])
     NUMBERS["bf16"] = num
     _dump()
-    # measured over several runs (ch=2: 8..32-channel layers, weights and states NOT bf16-representable; the runs differ among
-    # themselves -- these narrow layers' weight gradients go through fp32 atomics -- and step 1 sits behind an Adam update): losses
-    # 2.6e-3 / 3.7e-3; discriminator gradients 0.9999 / 0.9999 at step 0, 0.99997 / 0.9977 ... 0.9986 at step 1; generator gradient
-    # as one vector 0.9993 / 0.9999; the gradients that travel back through the recurrences -- the twelve state gradients and the
-    # early layers' weights -- 0.962 ... 0.992, the last stage's weights >= 0.9994 (cf. DESIGN.md section 2 on the one-ulp
-    # sensitivity of the early layers)
+    # measured (ch=2: 8..32-channel layers, weights and states NOT bf16-representable; step 1 sits behind an Adam update).  Since
+    # round 5 the step is bit-reproducible from run to run (every gradient is summed in a fixed order, see
+    # test_bf16_step_is_bitwise_reproducible), so these are single numbers, not ranges: losses 2.6e-3 / 3.7e-3; discriminator
+    # gradients 0.99986 / 0.99991 at step 0 and 0.99997 / 0.99856 at step 1; generator gradient as one vector 0.9992 / 0.99985;
+    # the gradients that travel back through the recurrences -- the twelve state gradients and the early layers' weights --
+    # 0.962 ... 0.992, the last stage's weights >= 0.9994 (cf. DESIGN.md section 2 on the one-ulp sensitivity of the early layers).
+    # (Round 4 needed a 0.98 sanity bound at step 1: D_t scattered 0.9941 ... 0.9986 over ten runs through fp32 atomics.)
     for s in range(len(out)):
         assert num[f"loss_err.{s}"] <= 2e-2, (s, num[f"loss_err.{s}"])
-        # step 0 is a pure forward / backward comparison; step 1 sits behind an Adam update of every weight and its gradients
-        # scatter from run to run (D_t 0.9941 ... 0.9986 over ten runs): a sanity bound only
-        dbound = 0.999 if s == 0 else 0.98
+        dbound = 0.999 if s == 0 else 0.997
         assert num[f"cos.{s}.Ds"] >= dbound and num[f"cos.{s}.Dt"] >= dbound, (s, num[f"cos.{s}.Ds"], num[f"cos.{s}.Dt"])
-        assert num[f"cos.{s}.G"] >= (0.995 if s == 0 else 0.98), (s, num[f"cos.{s}.G"])
+        assert num[f"cos.{s}.G"] >= (0.995 if s == 0 else 0.998), (s, num[f"cos.{s}.G"])
     for key, c in num.items():
         if not key.startswith("cos.0."):
             continue

@@ -494,3 +494,24 @@ def test_discriminators_on_even_frames_that_floor(size):
             if p.grad is not None:
                 v = sd[kk].grad
                 assert float((p.grad.double().cpu() - v.double()).norm()) < 2e-4 * float(v.norm()) + 1e-7, (kind, size, kk)
+
+
+def test_bf16_step_is_bitwise_reproducible():
+    """Two Trainers built from one seed take the same two bf16 steps (same clips, same RNG draws) at the benchmark's widths
+    (ch=32: the MFMA attention, the filter-row weight-gradient kernels, the ConvGRU wavefront with its in-launch split-K combine):
+    the six losses, every gradient the optimizers see and every parameter / spectral-norm / batch-norm buffer afterwards are
+    BIT-EQUAL.  Round 5: every weight, bias, condition and gamma gradient is summed in a fixed order (slice workspaces, per-block
+    partials, first-occurrence gathers) -- no fp32 atomics with more than one contribution per address remain on this path
+    (tools/repro_probe.py lists what differs; the fp64 batch-statistics atomics are the one exception)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("repro_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "repro_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    a = probe.run(32, 8, 2, 7, 2)
+    b = probe.run(32, 8, 2, 7, 2)
+    assert a[0] == b[0], (a[0], b[0])
+    assert len(a[1]) > 600
+    bad = [k for k in a[1] if not torch.equal(a[1][k], b[1][k])]
+    assert not bad, bad[:10]

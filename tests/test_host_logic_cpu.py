@@ -1,3 +1,4 @@
+import pytest
 """Host-side logic that needs no GPU: the learning-rate schedules of trainer.py:142-176 against torch's own
 schedulers and frame sampling against utils.py:60-63 semantics."""
 import torch
@@ -157,6 +158,37 @@ def test_ucf101_reader_host_side_matches_reference(tmp_path):
                 clip = clip.flip(2)
             got = ((clip.float().div(255) - 0.5) / 0.5).permute(3, 0, 1, 2).numpy()
             np.testing.assert_array_equal(got, g["out.clip." + tag], err_msg=tag)
+
+
+@pytest.mark.parametrize("n_samples", [0, -2, 1, 2, 3, 7])
+def test_make_dataset_windows_follow_the_reference_rule(tmp_path, n_samples):
+    """The clip windows of make_dataset for every n_samples_for_each_video, incl. the `< 1` branch (back-to-back windows,
+    Dataloader/datasets/ucf101.py:117-133), against a loop restating that rule."""
+    import json
+    import math
+    import os
+    from dvd_gan_amd import data as D
+    root = tmp_path / "jpg"
+    lengths = {"v_a": 40, "v_b": 17, "v_c": 5}
+    db = {}
+    for vid, n in lengths.items():
+        (root / "cls0" / vid).mkdir(parents=True)
+        (root / "cls0" / vid / "n_frames").write_text(str(n))
+        db[vid] = {"subset": "training", "annotations": {"label": "cls0"}}
+    ann = tmp_path / "ann.json"
+    ann.write_text(json.dumps({"labels": ["cls0"], "database": db}))
+    dur = 8
+    recs, names = D.make_dataset(str(root), str(ann), "training", n_samples, dur)
+    want = []
+    for vid, n in lengths.items():
+        if n_samples == 1:
+            want.append((vid, list(range(1, n + 1))))
+            continue
+        step = max(1, math.ceil((n - 1 - dur) / (n_samples - 1))) if n_samples > 1 else dur
+        for j in range(1, n, step):
+            want.append((vid, list(range(j, min(n + 1, j + dur)))))
+    assert [(r["video_id"], r["frame_indices"]) for r in recs] == want
+    assert names == {0: "cls0"}
 
 
 def test_bench_refuses_more_gpus_than_visible():
