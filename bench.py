@@ -59,6 +59,9 @@ def parse():
                     help="frame size; 128 = the Kinetics-600-shaped clips of BASELINE configs[3] (use --n-class 600)")
     ap.add_argument("--state-carry", action="store_true",
                     help="supply (and differentiate) initial ConvGRU states: the frame-conditional variant of BASELINE configs[4]")
+    ap.add_argument("--g-attn", default="none", choices=["none", "self", "sep", "both"],
+                    help="switch on the generator's optional attention blocks (Attention.py:114-185 SelfAttention over the (T, ld, ld) "
+                         "latent clip after the first ConvGRU / :8-111 SeparableAttn after module 8); off in the reference and in BASELINE's configs")
     ap.add_argument("--dp-mode", default="replica", choices=["replica", "global"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,7 +88,7 @@ def hbm_traffic(a, batch):
     """HBM bytes per launch of the dominant kernel family from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected
     with rocprofv3 in separate runs and corrected as MI355X_MICROARCH.md prescribes) -- only when they were taken on the
     shape being run; PMC collection cannot run inside the timed benchmark."""
-    best = None
+    best, src = None, None
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
         if not (name.endswith("hbm_traffic.json")):
             continue
@@ -95,9 +98,10 @@ def hbm_traffic(a, batch):
             shape = d.get("shape", {"size": 64, "frames": 48, "batch": 64, "ch": 32, "dtype": "bf16"})
             if shape == {"size": a.size, "frames": a.frames, "batch": batch, "ch": a.ch, "dtype": a.dtype}:
                 best = d["kernels"]["conv_igemm"]["hbm_bytes_per_launch_corrected"]      # latest round wins (sorted names)
+                src = "profiles/" + name
         except Exception:
             pass
-    return best
+    return best, src
 
 
 def cpu_baseline(a):
@@ -174,7 +178,8 @@ def main():
     for batch in candidates:
         cfg = argparse.Namespace(adv_loss="hinge", z_dim=120, g_chn=a.ch, ds_chn=a.ch, dt_chn=a.ch, n_frames=a.frames,
                                  lr_schr="const", total_epoch=1, d_iters=1, batch_size=batch, g_lr=5e-5, d_lr=5e-5,
-                                 beta1=0.0, beta2=0.9, n_class=a.n_class, k_sample=a.k_sample)
+                                 beta1=0.0, beta2=0.9, n_class=a.n_class, k_sample=a.k_sample,
+                                 g_self_attn=a.g_attn in ("self", "both"), g_sep_attn=a.g_attn in ("sep", "both"))
         try:
             torch.manual_seed(0)                               # (the Trainer broadcasts rank 0's model in any case)
             tr = Trainer([], cfg, device=dev, compute_dtype=dtype, latent_dim=a.size // 16, dp_mode=a.dp_mode)
@@ -251,11 +256,12 @@ def main():
                     by_kernel[vn] = {"launches": e["launches"], "ms": round(e["ms"], 1), "avg_us": round(e["avg_us"], 1),
                                      "achieved": round(e["tflops"], 1)}
         F = F_GFLOP_PER_CLIP.get((a.ch, a.frames, a.size))
+        traffic, traffic_src = hbm_traffic(a, batch)     # a committed PMC collection (tools/collect_evidence.sh), not this run
         dom = res["conv_igemm"]
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "kernel": "conv_halo_gb_kernel + conv_group_gb_kernel + conv_halo_gbs_kernel + conv_group_gbs_kernel + conv_igemm_kernel <bf16> (forward + backward-data convolutions)" if a.dtype == "bf16" else "conv_halo_kernel + conv_igemm_kernel <f32>",
                 "achieved": round(dom["tflops"], 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(dom["tflops"] / peak, 4), "traffic": hbm_traffic(a, batch),
+                "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["avg_us"], 1),
                 "gflop_per_launch": round(dom["gflop_per_launch"], 2), "kernel_ms_per_step": round(dom["ms"], 1),
                 "wgrad": {k: round(v, 2) if isinstance(v, float) else v for k, v in res["conv_wgrad"].items()},
@@ -276,6 +282,7 @@ def main():
                "config": {"workload": f"{kind}-shaped {a.n_class}-class {a.frames}x{a.size}x{a.size} clips, G+Ds+Dt hinge step, ch={a.ch}, "
                                       f"k_sample={a.k_sample}, batch {batch}/GPU"
                                       + (", initial ConvGRU states supplied and differentiated" if a.state_carry else "")
+                                      + (f", generator attention blocks ON ({a.g_attn}; not part of BASELINE's configs)" if a.g_attn != "none" else "")
                                       + f" (BASELINE configs[{cfg_id}])",
                           "global_batch": gB, "parallelism": f"dp{world}" + ("" if world == 1 else f" ({a.dp_mode} batch norm)")},
                "losses": [round(v, 4) for v in lossv],

@@ -16,7 +16,7 @@ for path in sorted(glob.glob(f"{pmc_dir}/**/*counter_collection.csv", recursive=
     for r in csv.DictReader(open(path)):
         kn = r["Kernel_Name"]
         # forward / backward-data family = halo-staged + tap-by-tap kernels; weight-gradient family = row + tap kernels
-        k = "conv_igemm" if ("conv_igemm" in kn or "conv_halo" in kn or "conv_thin" in kn) else "conv_wgrad" if ("conv_wgrad" in kn or "wgrad_thin" in kn) else "other"
+        k = "conv_igemm" if ("conv_igemm" in kn or "conv_halo" in kn or "conv_group" in kn or "conv_thin" in kn) else "conv_wgrad" if ("conv_wgrad" in kn or "wgrad_thin" in kn) else "other"
         agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
         short = kn.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
