@@ -271,14 +271,14 @@ static int attention_fwd(int dtype, const void* q, int ldq, int dq, const void* 
     return launch_status();
 }
 
-// dgamma += sum over all rows and channels of dy * att_out, ONE block in a fixed order (per-block partial sums added with fp32
-// atomics made the gradient of gamma differ from run to run)
+// dgamma += sum over all rows and channels of dy * att_out in a FIXED order: 256 blocks leave partial sums (in the dS scratch, dead
+// behind the column pass), one block adds them up (per-block atomics made the gradient of gamma differ from run to run)
 template <typename T>
-__global__ __launch_bounds__(1024) void attn_dgamma_kernel(const T* dy, const T* att_out, long long rows, int C, int ldx, float* dgamma) {
-    __shared__ float shw[16];
+__global__ __launch_bounds__(256) void attn_dgamma_partial_kernel(const T* dy, const T* att_out, long long rows, int C, int ldx, float* partial) {
+    __shared__ float shw[4];
     const int cg = C / 8;
     float a = 0.f;
-    for (long long i = threadIdx.x; i < rows * cg; i += 1024) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * cg; i += (long long)gridDim.x * 256) {
         const long long r = i / cg;
         const int c = (int)(i - r * cg) * 8;
         float u[8], v[8];
@@ -290,11 +290,13 @@ __global__ __launch_bounds__(1024) void attn_dgamma_kernel(const T* dy, const T*
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += shw[w];
-        *dgamma += t;
-    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = (shw[0] + shw[1]) + (shw[2] + shw[3]);
+}
+__global__ void attn_dgamma_final_kernel(const float* partial, int n, float* dgamma) {
+    if (threadIdx.x || blockIdx.x) return;
+    float t = 0.f;
+    for (int i = 0; i < n; ++i) t += partial[i];
+    *dgamma += t;
 }
 
 static int attention_bwd(int dtype, const void* q, int ldq, int dq, const void* kv, int ldk, int koff, int voff, const void* dy,
@@ -315,7 +317,11 @@ static int attention_bwd(int dtype, const void* q, int ldq, int dq, const void* 
     } while (0)
     if (qb == 16) ATT_BWD(16); else ATT_BWD(8);
 #undef ATT_BWD
-    if (dgamma) BY_DTYPE(dtype, attn_dgamma_kernel<T><<<1, 1024, 0, S_>>>((const T*)dy, (const T*)att_out, frames * N, C, ldx, dgamma));
+    if (dgamma) {
+        const int nb = (long long)frames * N * Nk >= 256 ? 256 : 1;          // partials live in dS ([frames][N][Nk] floats)
+        BY_DTYPE(dtype, attn_dgamma_partial_kernel<T><<<nb, 256, 0, S_>>>((const T*)dy, (const T*)att_out, frames * N, C, ldx, dS));
+        attn_dgamma_final_kernel<<<1, 64, 0, S_>>>(dS, nb, dgamma);
+    }
     return launch_status();
 }
 

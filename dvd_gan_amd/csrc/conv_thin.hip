@@ -16,7 +16,7 @@ constexpr int PG = 64;                    // pixels per group = 64 / W consecuti
 
 struct ThinFwdK {
     const bf16_t* in; const bf16_t* wt; const float* bias; const bf16_t* mask; bf16_t* out;
-    int ldmask, ldo, T, H, W, relu_in, act;
+    int ldmask, ldo, T, H, W, relu_in, act, out_f32;
     long long groups;
 };
 
@@ -89,6 +89,27 @@ __global__ __launch_bounds__(256) void conv_thin_in_kernel(ThinFwdK p) {
         // this lane: pixel `pix` of the group, out channels cb * 32 + 8 i + 4 h + {0..3} in registers 4 i .. 4 i + 3.  The tile goes
         // through LDS so that the rows leave as whole 128-byte lines (8-byte stores per lane straight from the accumulators touch 32
         // lines per instruction: 1.25 ms instead of 0.78 on the RGB layer's backward-data pass)
+        if (p.out_f32) {
+            // dvd_conv_desc.out_f32 (parity tests: the sums before the bf16 rounding, as the general kernels offer them): straight
+            // from the accumulators, 16 bytes per lane
+            const size_t row = (size_t)g * PG + pix;
+            float* o32 = reinterpret_cast<float*>(p.out) + row * p.ldo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = cb * 32 + 8 * i + 4 * h + e;
+                    float t = acc[4 * i + e] + b4[i][e];
+                    if (p.act == DVD_ACT_RELU) t = fmaxf(t, 0.f);
+                    if (p.mask && !(bf16_to_f32(p.mask[row * p.ldmask + c]) > 0.f)) t = 0.f;
+                    v[e] = t;
+                }
+                *reinterpret_cast<f32x4*>(o32 + cb * 32 + 8 * i + 4 * h) = v;
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v[4];
@@ -144,7 +165,7 @@ constexpr int OG = 128;                   // pixels per group
 
 struct ThinOutK {
     const bf16_t* in; const bf16_t* wt; const float* bias; const bf16_t* mask; bf16_t* out;
-    int ldi, ldmask, ldo, Cout, H, W, relu_in, act;
+    int ldi, ldmask, ldo, Cout, H, W, relu_in, act, out_f32;
     long long groups;
 };
 
@@ -209,7 +230,16 @@ __global__ __launch_bounds__(256) void conv_thin_out_kernel(ThinOutK p) {
             const float o = __shfl_xor(a, 32, 64);
             v[c] = h ? o : a; v[4 + c] = h ? a : o;
         }
-        if (h == 0) {
+        if (h == 0 && p.out_f32) {                       // dvd_conv_desc.out_f32 (parity tests): the sums before the bf16 rounding
+            const size_t row = (size_t)g * OG + pix;
+            if (p.mask)
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (!(bf16_to_f32(p.mask[row * p.ldmask + c]) > 0.f)) v[c] = 0.f;
+            float* o32 = reinterpret_cast<float*>(p.out) + row * p.ldo;
+            const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4*>(o32) = lo; *reinterpret_cast<f32x4*>(o32 + 4) = hi;
+        } else if (h == 0) {
             const size_t row = (size_t)g * OG + pix;
             u32x4 o;
             o.x = pack2_bf16(v[0], v[1]); o.y = pack2_bf16(v[2], v[3]); o.z = pack2_bf16(v[4], v[5]); o.w = pack2_bf16(v[6], v[7]);
@@ -244,7 +274,7 @@ __global__ void thin_out_image_kernel(const bf16_t* w, bf16_t* wt, int R) {
 int dvd_conv_thin_in_ok(const dvd_conv_desc* d) {
     constexpr int use = 1;
     if (!use || !d || d->dtype != DVD_BF16 || d->C != 8 || d->ldi != 8 || d->Cout != 64 || d->ldo < 64 || (d->ldo & 7)) return 0;
-    if (d->kh != 3 || d->kw != 3 || (d->kt != 1 && d->kt != 3) || d->up2 || d->res || d->ws || d->nsplit > 1 || d->out_f32) return 0;
+    if (d->kh != 3 || d->kw != 3 || (d->kt != 1 && d->kt != 3) || d->up2 || d->res || d->ws || d->nsplit > 1) return 0;
     if (d->act != DVD_ACT_NONE && d->act != DVD_ACT_RELU) return 0;
     if (d->W != 32 && d->W != 64) return 0;
     if (d->H % (PG / d->W) || d->frames < 1 || d->T < 1) return 0;
@@ -256,7 +286,7 @@ int dvd_conv_thin_in(const dvd_conv_desc* d, void* stream) {
     if (!dvd_conv_thin_in_ok(d) || !d->wq || !d->in || !d->out) return DVD_E_ARG;
     ThinFwdK p = {};
     p.in = (const bf16_t*)d->in; p.wt = (const bf16_t*)d->wq; p.bias = d->bias; p.mask = (const bf16_t*)d->mask; p.out = (bf16_t*)d->out;
-    p.ldmask = d->ldmask; p.ldo = d->ldo; p.T = d->T; p.H = d->H; p.W = d->W; p.relu_in = d->relu_in; p.act = d->act;
+    p.ldmask = d->ldmask; p.ldo = d->ldo; p.T = d->T; p.H = d->H; p.W = d->W; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     p.groups = (long long)d->frames * d->T * d->H * d->W / PG;
     const unsigned grid = (unsigned)(p.groups < 2048 ? p.groups : 2048);
     if (d->kt == 3) conv_thin_in_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(p);
@@ -276,7 +306,7 @@ extern "C" int dvd_conv_thin_image(const void* w, void* wt, int kt, void* stream
 int dvd_conv_thin_out_ok(const dvd_conv_desc* d) {
     constexpr int use = 1;
     if (!use || !d || d->dtype != DVD_BF16 || d->C != 64 || d->ldi < 64 || (d->ldi & 7) || d->Cout < 1 || d->Cout > 8 || d->ldo < 8 || (d->ldo & 7)) return 0;
-    if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->T != 1 || d->up2 || d->res || d->ws || d->nsplit > 1 || d->out_f32) return 0;
+    if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->T != 1 || d->up2 || d->res || d->ws || d->nsplit > 1) return 0;
     if (d->act != DVD_ACT_NONE && d->act != DVD_ACT_RELU && d->act != DVD_ACT_TANH) return 0;
     if (d->W != 32 && d->W != 64) return 0;
     if (d->H % (OG / d->W) || d->frames < 1) return 0;
@@ -288,7 +318,7 @@ int dvd_conv_thin_out(const dvd_conv_desc* d, void* stream) {
     if (!dvd_conv_thin_out_ok(d) || !d->wq || !d->in || !d->out) return DVD_E_ARG;
     ThinOutK p = {};
     p.in = (const bf16_t*)d->in; p.wt = (const bf16_t*)d->wq; p.bias = d->bias; p.mask = (const bf16_t*)d->mask; p.out = (bf16_t*)d->out;
-    p.ldi = d->ldi; p.ldmask = d->ldmask; p.ldo = d->ldo; p.Cout = d->Cout; p.H = d->H; p.W = d->W; p.relu_in = d->relu_in; p.act = d->act;
+    p.ldi = d->ldi; p.ldmask = d->ldmask; p.ldo = d->ldo; p.Cout = d->Cout; p.H = d->H; p.W = d->W; p.relu_in = d->relu_in; p.act = d->act; p.out_f32 = d->out_f32;
     p.groups = (long long)d->frames * d->H * d->W / OG;
     const unsigned grid = (unsigned)(p.groups < 512 ? p.groups : 512);
     conv_thin_out_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);

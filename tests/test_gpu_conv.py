@@ -194,6 +194,11 @@ def test_thin_input_convolution(case):
     ref = K.conv_forward(xc, pk.wf, ks, 64, bias=b.to(dev), act=act, relu_in=relu_in, mask=mc)
     assert rel(K.from_cl(got, 64).cpu(), want) < 3e-3
     assert rel(got.float().cpu(), ref.float().cpu()) < 1e-3       # same operands, fp32 sums in another order, one bf16 rounding
+    # the sums BEFORE the bf16 rounding (out_f32, as every other convolution is held to): only fp32 summation order is left
+    got32 = K.conv_forward(xc, pk.wf, ks, 64, bias=b.to(dev), act=act, relu_in=relu_in, mask=mc, out_f32=True,
+                           wq=lambda: pk.fragment_major("wf"))
+    assert got32.dtype == torch.float32
+    assert rel(K.from_cl(got32, 64).cpu(), want) < 2e-6
 
 
 @pytest.mark.parametrize("case", [(5, 64, True, 2), (3, 32, False, 0), (2, 64, False, 1)])
@@ -218,6 +223,9 @@ def test_thin_output_convolution(case):
     assert rel(K.from_cl(got, 3).cpu(), want) < 4e-3
     assert rel(got.float().cpu(), ref.float().cpu()) < 2e-3
     assert float(got[..., 3:].abs().max()) == 0.0                   # pad channels stay zero
+    got32 = K.conv_forward(xc, pk.wf, (3, 3), 3, bias=b.to(dev), act=act, relu_in=relu_in, out_f32=True, wq=lambda: pk.fragment_major("wf"))
+    assert got32.dtype == torch.float32 and float(got32[..., 3:].abs().max()) == 0.0
+    assert rel(K.from_cl(got32, 3).cpu(), want) < (2e-6 if act != 2 else 2e-5)     # (tanh: the bf16 mode's hardware exp / rcp form, ~1e-6 relative per value)
     # backward-data of a 3 -> 64 stem: dy [.., 64] through the flipped / transposed pack, masked by the stem's input
     ws = torch.randn(64, 3, 3, 3, generator=g) / 5.0
     xin = torch.randn(F_, 3, S, S, generator=g)
@@ -229,6 +237,8 @@ def test_thin_output_convolution(case):
     wdx = torch.nn.functional.conv_transpose2d(bf(x), bf(ws), padding=1) * (bf(xin) > 0)
     assert rel(K.from_cl(dx, 3).cpu(), wdx) < 4e-3
     assert rel(dx.float().cpu(), dx_ref.float().cpu()) < 2e-3
+    dx32 = K.conv_forward(xc, ps.wd, (3, 3), ps.cip, mask=mc, out_f32=True, wq=lambda: ps.fragment_major("wd"))
+    assert rel(K.from_cl(dx32, 3).cpu(), wdx) < 2e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
