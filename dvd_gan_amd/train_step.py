@@ -381,7 +381,7 @@ class Trainer(object):
                 self.save_models(step)
 
     # ---- trainer.py:323-334: the sampling path (eval-mode G on fixed z / labels, BN running statistics), without
-    # the image-file side (torchvision save_image / tensorboard are host plumbing, DESIGN section 7)
+    # the image-file side (torchvision save_image / tensorboard are host plumbing, DESIGN section 8)
     @torch.no_grad()
     def sample(self, fixed_z, fixed_label):
         """-> denorm(G(fixed_z, fixed_label)) [B, T, 3, H, W] in [0, 1]; G is put back in train mode, like the reference.

@@ -12,7 +12,7 @@ channels, T=48, 64x64, 101 classes, k=8, hinge) with B=2.
   * bf16 mode, free-running full step: the six losses and the discriminator outputs.
   * the sensitivity measurement behind the tolerances, as an asserting test.
 
-The stated tolerances are the table in DESIGN.md section 2; measured values are written to
+The stated tolerances are the table in profiles/HISTORY.md (rounds 1-4, section 2; summary in DESIGN.md section 2); measured values are written to
 gpurun_out/fullwidth_numbers.json when that directory exists.
 """
 import argparse

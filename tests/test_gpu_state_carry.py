@@ -181,7 +181,7 @@ def test_state_carry_step_bf16(golden):
     # test_bf16_step_is_bitwise_reproducible), so these are single numbers, not ranges: losses 2.6e-3 / 3.7e-3; discriminator
     # gradients 0.99986 / 0.99991 at step 0 and 0.99997 / 0.99856 at step 1; generator gradient as one vector 0.9992 / 0.99985;
     # the gradients that travel back through the recurrences -- the twelve state gradients and the early layers' weights --
-    # 0.962 ... 0.992, the last stage's weights >= 0.9994 (cf. DESIGN.md section 2 on the one-ulp sensitivity of the early layers).
+    # 0.962 ... 0.992, the last stage's weights >= 0.9994 (cf. DESIGN.md section 2 / profiles/HISTORY.md on the one-ulp sensitivity of the early layers).
     # (Round 4 needed a 0.98 sanity bound at step 1: D_t scattered 0.9941 ... 0.9986 over ten runs through fp32 atomics.)
     for s in range(len(out)):
         assert num[f"loss_err.{s}"] <= 2e-2, (s, num[f"loss_err.{s}"])
