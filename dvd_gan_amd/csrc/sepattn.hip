@@ -13,6 +13,8 @@
 // index arithmetic of the reshapes, the small products run on them, and `scatter` routes the gradients back (the max-pool
 // gradient goes to the first maximum of each pair, like F.max_pool3d).  The block is defined by the reference but not
 // invoked by its generator; it is < 0.1 % of a step's FLOPs when enabled, so everything is plain fp32 on the vector pipe.
+// Round 5: the two small products run as tiled products (sep_prod_kernel); the gather / scatter / output kernels are still one
+// thread per flat element with 2-byte scattered accesses (bench.py --g-attn sep shows what that costs).
 #include "common.h"
 
 namespace {
@@ -100,27 +102,80 @@ __device__ float blk_sum256(float v, float* sh) {
     return t;
 }
 
-// att[b][a][:] = softmax_j( sum_l Qf[a*L + l] * Kp[l*(A/2) + j] );  grid (A, B), 256 threads, A/2 <= 64
-__global__ __launch_bounds__(256) void sep_scores_kernel(SepGeo g, const float* Qf, const float* Kp, float* att) {
-    __shared__ float sh[4];
-    __shared__ float sc[64];
-    const int a = blockIdx.x, Ah = g.A / 2;
-    const long long b = blockIdx.y, L = (long long)g.Cq * g.D1 * g.D2;
-    const float* q = Qf + b * g.A * L + (long long)a * L;
-    const float* k = Kp + b * L * Ah;
-    for (int j = 0; j < Ah; ++j) {
-        float s = 0.f;
-        for (long long l = threadIdx.x; l < L; l += 256) s += q[l] * k[l * Ah + j];
-        s = blk_sum256(s, sh);
-        if (threadIdx.x == 0) sc[j] = s;
+// The two [A][A/2] products of a cell -- scores[a][j] = sum_l Qf[a*L + l] * Kp[l*(A/2) + j] (forward) and
+// datt[a][j] = sum_r dO[r*A + a] * Vp[r*(A/2) + j] (backward) -- as tiled products (round 5; the first form ran one block per
+// output row a with a block reduction per column j over STRIDED operand columns: 29 / 194 ms per call at 48 x 32 x 32, C = 128).
+// Block (split s of the long axis, clip b), 1024 threads: 64 rows of both operands at a time through LDS (coalesced loads; the
+// first operand is stored [l][a] whichever way it lies in memory), thread = (4 x 4 block of outputs, one of 8 row lanes), the 8 row
+// lanes folded by a fixed butterfly.  P[b][s][a][j] = the partial sums of split s, added in split order by the finishing kernels.
+constexpr int kSepSplit = 8, kSepRows = 64;
+template <bool FIRST_ROWS>      // true: U[a*L + l] (Qf), false: U[l*A + a] (dO)
+__global__ __launch_bounds__(1024) void sep_prod_kernel(const float* U, const float* V, float* P, int A, int Ah, long long L) {
+    __shared__ float Ut[kSepRows][68];              // [l][a], a < 64 (+4: rows 16-byte aligned, banks spread)
+    __shared__ float Vt[kSepRows][36];              // [l][j], j < 32
+    const int tid = threadIdx.x, s = blockIdx.x;
+    const long long b = blockIdx.y;
+    U += b * A * L; V += b * L * Ah;
+    const int SJ = (Ah + 3) / 4, NSB = ((A + 3) / 4) * SJ;
+    const int ll = tid & 7, sb = tid >> 3;
+    const bool live = sb < NSB;
+    const int a0 = (sb / SJ) * 4, j0 = (sb % SJ) * 4;
+    long long per = (L + kSepSplit - 1) / kSepSplit;
+    per = (per + kSepRows - 1) / kSepRows * kSepRows;
+    const long long l0 = s * per, l1 = l0 + per < L ? l0 + per : L;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (long long lc = l0; lc < l1; lc += kSepRows) {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * kSepRows; idx += 1024) {      // first operand, zero-padded to 64 columns
+            int a, l;
+            if (FIRST_ROWS) { a = idx / kSepRows; l = idx - a * kSepRows; } else { l = idx / 64; a = idx - l * 64; }
+            float v = 0.f;
+            if (a < A && lc + l < l1) v = FIRST_ROWS ? U[(long long)a * L + lc + l] : U[(lc + l) * A + a];
+            Ut[l][a] = v;
+        }
+        for (int idx = tid; idx < 32 * kSepRows; idx += 1024) {      // second operand, zero-padded to 32 columns
+            const int l = idx >> 5, j = idx & 31;
+            Vt[l][j] = (j < Ah && lc + l < l1) ? V[(lc + l) * Ah + j] : 0.f;
+        }
+        __syncthreads();
+        if (live)
+#pragma unroll
+            for (int l = ll; l < kSepRows; l += 8) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(&Ut[l][a0]);
+                const f32x4 k = *reinterpret_cast<const f32x4*>(&Vt[l][j0]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += q[i] * k[j];
+            }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = -INFINITY, sum = 0.f;
-        for (int j = 0; j < Ah; ++j) m = fmaxf(m, sc[j]);
-        for (int j = 0; j < Ah; ++j) { sc[j] = expf(sc[j] - m); sum += sc[j]; }
-        for (int j = 0; j < Ah; ++j) att[(b * g.A + a) * Ah + j] = sc[j] / sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[i][j];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            if (live && ll == 0 && a0 + i < A && j0 + j < Ah) P[((b * kSepSplit + s) * A + a0 + i) * Ah + j0 + j] = v;
+        }
+}
+
+// att[b][a][:] = softmax_j of the summed score partials;  grid (A, B), one wave
+__global__ __launch_bounds__(64) void sep_softmax_kernel(const float* P, float* att, int A, int Ah) {
+    const int a = blockIdx.x, j = threadIdx.x;
+    const long long b = blockIdx.y;
+    float sc = -INFINITY;
+    if (j < Ah) {
+        sc = 0.f;
+        for (int s = 0; s < kSepSplit; ++s) sc += P[((b * kSepSplit + s) * A + a) * Ah + j];
     }
+    const float m = wave_max(sc);
+    const float e = j < Ah ? expf(sc - m) : 0.f;
+    const float sum = wave_sum(e);
+    if (j < Ah) att[(b * A + a) * Ah + j] = e / sum;
 }
 
 // y = gamma * out + x with out[r][a] = sum_j Vp[r*(A/2)+j] * att[a][j];  one thread per flat output index
@@ -171,27 +226,17 @@ __global__ __launch_bounds__(256) void sep_dout_kernel(SepGeo g, const float* Vp
     if (threadIdx.x == 0 && part != 0.f) atomicAdd(dgamma, part);
 }
 
-// dS[b][a][:] = softmax backward of datt[a][j] = sum_r dO[r*A + a] * Vp[r*(A/2) + j];  grid (A, B)
-__global__ __launch_bounds__(256) void sep_datt_kernel(SepGeo g, const float* dO, const float* Vp, const float* att, float* dS) {
-    __shared__ float sh[4];
-    __shared__ float da[64];
-    const int a = blockIdx.x, Ah = g.A / 2;
-    const long long b = blockIdx.y, R = (long long)g.C * g.D1 * g.D2;
-    const float* d = dO + b * R * g.A;
-    const float* v = Vp + b * R * Ah;
-    for (int j = 0; j < Ah; ++j) {
-        float s = 0.f;
-        for (long long r = threadIdx.x; r < R; r += 256) s += d[r * g.A + a] * v[r * Ah + j];
-        s = blk_sum256(s, sh);
-        if (threadIdx.x == 0) da[j] = s;
+// dS[b][a][:] = softmax backward of the summed datt partials (sep_prod_kernel<false> over dO, Vp);  grid (A, B), one wave
+__global__ __launch_bounds__(64) void sep_dsoft_kernel(const float* P, const float* att, float* dS, int A, int Ah) {
+    const int a = blockIdx.x, j = threadIdx.x;
+    const long long b = blockIdx.y;
+    float da = 0.f, at = 0.f;
+    if (j < Ah) {
+        for (int s = 0; s < kSepSplit; ++s) da += P[((b * kSepSplit + s) * A + a) * Ah + j];
+        at = att[(b * A + a) * Ah + j];
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float* at = att + (b * g.A + a) * Ah;
-        float dot = 0.f;
-        for (int j = 0; j < Ah; ++j) dot += da[j] * at[j];
-        for (int j = 0; j < Ah; ++j) dS[(b * g.A + a) * Ah + j] = at[j] * (da[j] - dot);
-    }
+    const float dot = wave_sum(da * at);
+    if (j < Ah) dS[(b * A + a) * Ah + j] = at * (da - dot);
 }
 
 // gradients of the three flat operands; one thread per element of (dQf | dKp | dVp)
@@ -276,7 +321,7 @@ static int sep_check(int T, int W, int H, int axis, int C, int Cq) {
     if (T <= 0 || W <= 0 || H <= 0 || C <= 0 || Cq <= 0 || axis < 0 || axis > 2) return DVD_E_ARG;
     if ((T | W | H) & 1) return DVD_E_SHAPE;                       // Attention.py:67: "T, W, H is not even"
     const int A = axis == 0 ? T : axis == 1 ? W : H;
-    if (A / 2 > 64) return DVD_E_SHAPE;
+    if (A > 64) return DVD_E_SHAPE;                                 // (tiles of sep_prod_kernel: 64 x 32 outputs)
     return DVD_OK;
 }
 
@@ -296,7 +341,13 @@ extern "C" int dvd_sepattn_forward(int dtype, const void* qkv, int ldq, int Cq, 
     const long long per = (long long)Cq * g.N * 3 / 2 + (long long)C * g.N / 2;
     BY_DTYPE(dtype, sep_gather_kernel<T><<<cdiv(B * per, 256), 256, 0, S_>>>(g, (const T*)qkv, ldq, koff, voff, Qf, Kp, Vp,
                                                                              ksel, vsel, B));
-    sep_scores_kernel<<<dim3(g.A, (unsigned)B), 256, 0, S_>>>(g, Qf, Kp, att);
+    // the partial score sums live in `y` until sep_out_kernel writes it (B * 8 * A * A/2 floats; y holds B * N * ldx elements)
+    float* part = reinterpret_cast<float*>(y);
+    if ((long long)kSepSplit * g.A * (g.A / 2) * 4 > g.N * ldx * (dtype == DVD_BF16 ? 2 : 4)) return DVD_E_SHAPE;       // (never: N >= 8 A)
+    sep_prod_kernel<true><<<dim3(kSepSplit, (unsigned)B), 1024, 0, S_>>>(Qf, Kp, part, g.A, g.A / 2, (long long)Cq * g.D1 * g.D2);
+    sep_softmax_kernel<<<dim3(g.A, (unsigned)B), 64, 0, S_>>>(part, att, g.A, g.A / 2);
+    if (ldx != C &&      // padded channel columns of y must read zero afterwards (sep_out_kernel writes the real ones only)
+        hipMemsetAsync(y, 0, (size_t)B * kSepSplit * g.A * (g.A / 2) * sizeof(float), S_) != hipSuccess) return DVD_E_LAUNCH;
     BY_DTYPE(dtype, sep_out_kernel<T><<<cdiv(B * C * g.N, 256), 256, 0, S_>>>(g, Vp, att, (const T*)x, ldx, gamma, (T*)y, B));
     return launch_status();
 }
@@ -315,7 +366,10 @@ extern "C" int dvd_sepattn_backward(int dtype, const void* dy, int ldx, int C, i
     const long long per = (long long)Cq * g.N * 3 / 2 + (long long)C * g.N / 2;
     BY_DTYPE(dtype, sep_dout_kernel<T><<<cdiv(B * C * g.N, 256), 256, 0, S_>>>(g, Vp, att, (const T*)dy, ldx, gamma, dO,
                                                                                dgamma, B));
-    sep_datt_kernel<<<dim3(g.A, (unsigned)B), 256, 0, S_>>>(g, dO, Vp, att, dS);
+    // the partial sums of datt live in dQf until sep_dops_kernel writes it (B * 8 * A * A/2 of its B * Cq * N floats)
+    if ((long long)kSepSplit * g.A * (g.A / 2) > (long long)Cq * g.N) return DVD_E_SHAPE;
+    sep_prod_kernel<false><<<dim3(kSepSplit, (unsigned)B), 1024, 0, S_>>>(dO, Vp, dQf, g.A, g.A / 2, (long long)C * g.D1 * g.D2);
+    sep_dsoft_kernel<<<dim3(g.A, (unsigned)B), 64, 0, S_>>>(dQf, att, dS, g.A, g.A / 2);
     sep_dops_kernel<<<cdiv(B * per, 256), 256, 0, S_>>>(g, dO, att, dS, Qf, Kp, dQf, dKp, dVp, B);
     BY_DTYPE(dtype, sep_scatter_kernel<T><<<cdiv(B * g.N * (2 * Cq + C), 256), 256, 0, S_>>>(
                         g, dQf, dKp, dVp, ksel, vsel, (T*)dqkv, ldq, koff, voff, B));
