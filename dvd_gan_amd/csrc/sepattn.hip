@@ -59,36 +59,48 @@ __device__ __forceinline__ void out_dest(const SepGeo& g, long long o, int& c, l
     }
 }
 
-// one thread per element of Qf, Kp, Vp (in that order)
-template <typename T>
-__global__ void sep_gather_kernel(SepGeo g, const T* qkv, int ldq, int koff, int voff, float* Qf, float* Kp, float* Vp,
-                                  unsigned char* ksel, unsigned char* vsel, long long B) {
-    const long long nq = (long long)g.Cq * g.N, nk = nq / 2, nv = (long long)g.C * g.N / 2, per = nq + nk + nv;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * per) return;
-    const long long b = i / per;
-    long long e = i - b * per;
+// Qf, Kp, Vp (+ the max-pool winners) from the channels-last projection.  Round 5: a tile of TP positions of the (d1, d2) plane for
+// the two attended coordinates 2 dp, 2 dp + 1 goes through LDS -- the rows of `qkv` are read along their channels (coalesced), the
+// flat operands are written along the plane (TP consecutive floats per channel).  The first form (one thread per flat element)
+// read 2 bytes from a different 512-byte row in every lane.
+template <typename T, int TP>
+__global__ __launch_bounds__(256) void sep_gather_kernel(SepGeo g, const T* qkv, int ldq, int koff, int voff, float* Qf, float* Kp, float* Vp,
+                                                         unsigned char* ksel, unsigned char* vsel) {
+    extern __shared__ float tile[];                 // [2][TP][NC + 1]
+    const int NC = 2 * g.Cq + g.C, NCP = NC + 1;
+    const int PL = g.D1 * g.D2, Ah = g.A / 2;
+    const int p0 = blockIdx.x * TP, dp = blockIdx.y, tid = threadIdx.x;
+    const long long b = blockIdx.z;
+    const long long nq = (long long)g.Cq * g.N, nk = nq / 2, nv = (long long)g.C * g.N / 2;
     const T* base = qkv + (size_t)b * g.N * ldq;
-    if (e < nq) {
-        const int d2 = (int)(e % g.D2); long long r = e / g.D2;
-        const int d1 = (int)(r % g.D1); r /= g.D1;
-        const int d0 = (int)(r % g.A); const int c = (int)(r / g.A);
-        Qf[b * nq + e] = ldf(base + (size_t)token(g, d0, d1, d2) * ldq + c);
-        return;
+    for (int idx = tid; idx < 2 * TP * NC; idx += 256) {
+        const int col = idx % NC, rp = idx / NC, p = rp % TP, s2 = rp / TP;
+        float v = 0.f;
+        if (p0 + p < PL) {
+            const int pos = p0 + p, d1 = pos / g.D2, d2 = pos - d1 * g.D2;
+            const int src = col < g.Cq ? col : col < 2 * g.Cq ? koff + col - g.Cq : voff + col - 2 * g.Cq;
+            v = ldf(base + (size_t)token(g, 2 * dp + s2, d1, d2) * ldq + src);
+        }
+        tile[(s2 * TP + p) * NCP + col] = v;
     }
-    e -= nq;
-    const bool isv = e >= nk;
-    if (isv) e -= nk;
-    const int Ah = g.A / 2;
-    const int d2 = (int)(e % g.D2); long long r = e / g.D2;
-    const int d1 = (int)(r % g.D1); r /= g.D1;
-    const int dp = (int)(r % Ah); const int c = (int)(r / Ah);
-    const int col = (isv ? voff : koff) + c;
-    const float a0 = ldf(base + (size_t)token(g, 2 * dp, d1, d2) * ldq + col);
-    const float a1 = ldf(base + (size_t)token(g, 2 * dp + 1, d1, d2) * ldq + col);
-    const bool second = a1 > a0;                                 // ties -> the first element, like F.max_pool3d
-    if (isv) { Vp[b * nv + e] = second ? a1 : a0; vsel[b * nv + e] = second; }
-    else { Kp[b * nk + e] = second ? a1 : a0; ksel[b * nk + e] = second; }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * g.Cq * TP; idx += 256) {          // q: both attended coordinates
+        const int p = idx % TP, r = idx / TP, c = r % g.Cq, s2 = r / g.Cq;
+        if (p0 + p < PL) Qf[b * nq + ((long long)c * g.A + 2 * dp + s2) * PL + p0 + p] = tile[(s2 * TP + p) * NCP + c];
+    }
+    for (int idx = tid; idx < (g.Cq + g.C) * TP; idx += 256) {      // k, v: max over the pair; ties -> the first element, like F.max_pool3d
+        const int p = idx % TP, c = idx / TP;
+        if (p0 + p >= PL) continue;
+        const float a0 = tile[p * NCP + g.Cq + c], a1 = tile[(TP + p) * NCP + g.Cq + c];
+        const bool second = a1 > a0;
+        if (c < g.Cq) {
+            const long long e = ((long long)c * Ah + dp) * PL + p0 + p;
+            Kp[b * nk + e] = second ? a1 : a0; ksel[b * nk + e] = second;
+        } else {
+            const long long e = ((long long)(c - g.Cq) * Ah + dp) * PL + p0 + p;
+            Vp[b * nv + e] = second ? a1 : a0; vsel[b * nv + e] = second;
+        }
+    }
 }
 
 __device__ float blk_sum256(float v, float* sh) {
@@ -178,52 +190,72 @@ __global__ __launch_bounds__(64) void sep_softmax_kernel(const float* P, float* 
     if (j < Ah) att[(b * A + a) * Ah + j] = e / sum;
 }
 
-// y = gamma * out + x with out[r][a] = sum_j Vp[r*(A/2)+j] * att[a][j];  one thread per flat output index
-template <typename T>
-__global__ void sep_out_kernel(SepGeo g, const float* Vp, const float* att, const T* x, int ldx, const float* gamma, T* y,
-                               long long B) {
-    const long long per = (long long)g.C * g.N;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * per) return;
-    const long long b = i / per, o = i - b * per;
-    const int Ah = g.A / 2;
-    const long long r = o / g.A;
-    const int a = (int)(o - r * g.A);
-    const float* v = Vp + b * (per / 2) + r * Ah;
-    const float* at = att + (b * g.A + a) * Ah;
-    float s = 0.f;
-    for (int j = 0; j < Ah; ++j) s += v[j] * at[j];
-    int c; long long tok;
-    out_dest(g, o, c, tok);
-    const size_t off = ((size_t)b * g.N + tok) * ldx + c;
-    stf(y + off, *gamma * s + ldf(x + off));
-}
-
-// dO[b][o] = gamma * dy[dest(o)];  dgamma += sum dy * out
-template <typename T>
-__global__ __launch_bounds__(256) void sep_dout_kernel(SepGeo g, const float* Vp, const float* att, const T* dy, int ldx,
-                                                       const float* gamma, float* dO, float* dgamma, long long B) {
+// y = gamma * out + x with out[r][a] = sum_j Vp[r*(A/2)+j] * att[a][j], out [R][A] viewed as [C, E1, E2, E3] (Attention.py:101-106).
+// Round 5: a block owns QT rows r of each of 32 channels (r = c * (N / A) + q): thread (channel, q) keeps its Vp row in registers
+// and produces the A outputs of its row, the tile goes through LDS and leaves as 64-byte channel runs of the destination tokens
+// (the first form wrote -- and read x -- 2 bytes per lane into a different token row each).  sep_dout_kernel is the same tiling in
+// the other direction: dy rows in, dO[r][0..A) out, and the partial sums of dgamma.
+constexpr int kSepCB = 32;
+__device__ __forceinline__ int sep_qt(int A) { return A <= 16 ? 8 : A <= 32 ? 4 : A <= 48 ? 4 : 2; }        // QT * A <= 256 tile rows ... (A <= 64)
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(256) void sep_outio_kernel(SepGeo g, const float* Vp, const float* att, const T* xy, int ldx, const float* gamma,
+                                                        T* y, float* dO, float* dgamma) {
+    __shared__ float att_s[64 * 32];
+    __shared__ float tile[256][kSepCB + 1];
     __shared__ float sh[4];
-    const long long per = (long long)g.C * g.N;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    float part = 0.f;
-    if (i < B * per) {
-        const long long b = i / per, o = i - b * per;
-        const int Ah = g.A / 2;
-        const long long r = o / g.A;
-        const int a = (int)(o - r * g.A);
-        const float* v = Vp + b * (per / 2) + r * Ah;
-        const float* at = att + (b * g.A + a) * Ah;
-        float s = 0.f;
-        for (int j = 0; j < Ah; ++j) s += v[j] * at[j];
-        int c; long long tok;
-        out_dest(g, o, c, tok);
-        const float d = ldf(dy + ((size_t)b * g.N + tok) * ldx + c);
-        dO[i] = *gamma * d;
-        part = d * s;
+    const int A = g.A, Ah = A / 2, QT = sep_qt(A);
+    const long long PLr = g.N / A, per = (long long)g.C * g.N;
+    const long long b = blockIdx.z;
+    const int q0 = blockIdx.x * QT, c0 = blockIdx.y * kSepCB, tid = threadIdx.x;
+    const int cl = tid & (kSepCB - 1), ql = tid >> 5;
+    for (int i = tid; i < A * Ah; i += 256) att_s[i] = att[b * A * Ah + i];
+    const bool live = ql < QT && q0 + ql < PLr && c0 + cl < g.C;
+    const long long r = (long long)(c0 + cl) * PLr + q0 + ql;
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = (live && j < Ah) ? Vp[b * (per / 2) + r * Ah + j] : 0.f;
+    const float gm = *gamma;
+    if (BACKWARD) {                                   // dy rows of the tile's tokens -> LDS (channel runs)
+        for (int idx = tid; idx < QT * A * kSepCB; idx += 256) {
+            const int c = idx & (kSepCB - 1), row = idx >> 5, qq = row / A, a = row - qq * A;
+            float d = 0.f;
+            if (q0 + qq < PLr && c0 + c < g.C) {
+                int cc; long long tok;
+                out_dest(g, ((long long)c0 * PLr + q0 + qq) * A + a, cc, tok);          // (the token does not depend on the channel)
+                d = ldf(xy + ((size_t)b * g.N + tok) * ldx + c0 + c);
+            }
+            tile[row][c] = d;
+        }
     }
-    part = blk_sum256(part, sh);
-    if (threadIdx.x == 0 && part != 0.f) atomicAdd(dgamma, part);
+    __syncthreads();
+    float part = 0.f;
+    if (live || !BACKWARD)
+        for (int a = 0; a < A; ++a) {
+            float o = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) o += v[j] * att_s[a * Ah + (j < Ah ? j : 0)] * (j < Ah ? 1.f : 0.f);
+            if (BACKWARD) {
+                if (live) {
+                    const float d = tile[ql * A + a][cl];
+                    dO[b * per + r * A + a] = gm * d;
+                    part += d * o;
+                }
+            } else if (ql < QT) tile[ql * A + a][cl] = o;
+        }
+    if (BACKWARD) {
+        part = blk_sum256(part, sh);
+        if (tid == 0 && part != 0.f) atomicAdd(dgamma, part);
+        return;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < QT * A * kSepCB; idx += 256) {
+        const int c = idx & (kSepCB - 1), row = idx >> 5, qq = row / A, a = row - qq * A;
+        if (q0 + qq >= PLr || c0 + c >= g.C) continue;
+        int cc; long long tok;
+        out_dest(g, ((long long)c0 * PLr + q0 + qq) * A + a, cc, tok);
+        const size_t off = ((size_t)b * g.N + tok) * ldx + c0 + c;
+        stf(y + off, gm * tile[row][c] + ldf(xy + off));
+    }
 }
 
 // dS[b][a][:] = softmax backward of the summed datt partials (sep_prod_kernel<false> over dO, Vp);  grid (A, B), one wave
@@ -239,72 +271,92 @@ __global__ __launch_bounds__(64) void sep_dsoft_kernel(const float* P, const flo
     if (j < Ah) dS[(b * A + a) * Ah + j] = at * (da - dot);
 }
 
-// gradients of the three flat operands; one thread per element of (dQf | dKp | dVp)
-__global__ void sep_dops_kernel(SepGeo g, const float* dO, const float* att, const float* dS, const float* Qf, const float* Kp,
-                                float* dQf, float* dKp, float* dVp, long long B) {
-    const long long nq = (long long)g.Cq * g.N, nk = nq / 2, nv = (long long)g.C * g.N / 2, per = nq + nk + nv;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * per) return;
-    const long long b = i / per;
-    long long e = i - b * per;
-    const int Ah = g.A / 2;
-    const long long L = nq / g.A;
-    if (e < nq) {                                   // dQf[a*L + l] = sum_j dS[a][j] * Kp[l*(A/2) + j]
-        const long long a = e / L, l = e - a * L;
-        const float* ds = dS + (b * g.A + a) * Ah;
-        const float* k = Kp + b * nk + l * Ah;
+// gradients of the flat operands.  Round 5: one thread per ROW of the long axis (l of Qf / Kp, r of dO / Vp) with dS / att in LDS, so
+// every global access is a per-thread contiguous run or coalesced across the block:
+//   dQf[a*L + l] = sum_j dS[a][j] * Kp[l*(A/2) + j];   dKp[l*(A/2) + j] = sum_a dS[a][j] * Qf[a*L + l]      (thread l)
+//   dVp[r*(A/2) + j] = sum_a dO[r*A + a] * att[a][j]                                                        (thread r)
+__global__ __launch_bounds__(256) void sep_dqk_kernel(SepGeo g, const float* dS, const float* Qf, const float* Kp, float* dQf, float* dKp) {
+    __shared__ float ds_s[64 * 32];
+    const int A = g.A, Ah = A / 2;
+    const long long b = blockIdx.y, L = (long long)g.Cq * g.N / A;
+    const long long nq = (long long)g.Cq * g.N, nk = nq / 2;
+    for (int i = threadIdx.x; i < A * Ah; i += 256) ds_s[i] = dS[b * A * Ah + i];
+    __syncthreads();
+    const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    float k[32], dk[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { k[j] = j < Ah ? Kp[b * nk + l * Ah + j] : 0.f; dk[j] = 0.f; }
+    for (int a = 0; a < A; ++a) {
+        const float q = Qf[b * nq + (long long)a * L + l];
         float s = 0.f;
-        for (int j = 0; j < Ah; ++j) s += ds[j] * k[j];
-        dQf[b * nq + e] = s;
-        return;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float d = j < Ah ? ds_s[a * Ah + j] : 0.f;
+            s += d * k[j];
+            dk[j] += d * q;
+        }
+        dQf[b * nq + (long long)a * L + l] = s;
     }
-    e -= nq;
-    if (e < nk) {                                   // dKp[l*(A/2) + j] = sum_a dS[a][j] * Qf[a*L + l]
-        const long long l = e / Ah;
-        const int j = (int)(e - l * Ah);
-        float s = 0.f;
-        for (int a = 0; a < g.A; ++a) s += dS[(b * g.A + a) * Ah + j] * Qf[b * nq + (long long)a * L + l];
-        dKp[b * nk + e] = s;
-        return;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+        if (j < Ah) dKp[b * nk + l * Ah + j] = dk[j];
+}
+__global__ __launch_bounds__(256) void sep_dv_kernel(SepGeo g, const float* dO, const float* att, float* dVp) {
+    __shared__ float att_s[64 * 32];
+    const int A = g.A, Ah = A / 2;
+    const long long b = blockIdx.y, R = (long long)g.C * g.N / A, nv = (long long)g.C * g.N / 2;
+    for (int i = threadIdx.x; i < A * Ah; i += 256) att_s[i] = att[b * A * Ah + i];
+    __syncthreads();
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float dv[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) dv[j] = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float d = dO[b * 2 * nv + r * A + a];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) dv[j] += d * (j < Ah ? att_s[a * Ah + j] : 0.f);
     }
-    e -= nk;                                        // dVp[r*(A/2) + j] = sum_a dO[r*A + a] * att[a][j]
-    const long long r = e / Ah;
-    const int j = (int)(e - r * Ah);
-    float s = 0.f;
-    for (int a = 0; a < g.A; ++a) s += dO[b * 2 * nv + r * g.A + a] * att[(b * g.A + a) * Ah + j];
-    dVp[b * nv + e] = s;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+        if (j < Ah) dVp[b * nv + r * Ah + j] = dv[j];
 }
 
-// dqkv (channels-last, q | k | v columns; other columns untouched) from the flat gradients
-template <typename T>
-__global__ void sep_scatter_kernel(SepGeo g, const float* dQf, const float* dKp, const float* dVp, const unsigned char* ksel,
-                                   const unsigned char* vsel, T* dqkv, int ldq, int koff, int voff, long long B) {
-    const int ncol = 2 * g.Cq + g.C;
-    const long long per = g.N * ncol;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * per) return;
-    const long long b = i / per, e = i - b * per;
-    const long long tok = e / ncol;
-    int cc = (int)(e - tok * ncol);
-    const int h = (int)(tok % g.H), w = (int)((tok / g.H) % g.W), t = (int)(tok / ((long long)g.H * g.W));
-    int d0, d1, d2;
-    if (g.axis == 0) { d0 = t; d1 = w; d2 = h; }
-    else if (g.axis == 1) { d0 = w; d1 = t; d2 = h; }
-    else { d0 = h; d1 = w; d2 = t; }
+// dqkv (channels-last, q | k | v columns; other columns untouched) from the flat gradients: the tiling of sep_gather_kernel in the
+// other direction (the max-pool gradient goes to the remembered winner of each pair)
+template <typename T, int TP>
+__global__ __launch_bounds__(256) void sep_scatter_kernel(SepGeo g, const float* dQf, const float* dKp, const float* dVp, const unsigned char* ksel,
+                                                          const unsigned char* vsel, T* dqkv, int ldq, int koff, int voff) {
+    extern __shared__ float tile[];                 // [2][TP][NC + 1]
+    const int NC = 2 * g.Cq + g.C, NCP = NC + 1;
+    const int PL = g.D1 * g.D2, Ah = g.A / 2;
+    const int p0 = blockIdx.x * TP, dp = blockIdx.y, tid = threadIdx.x;
+    const long long b = blockIdx.z;
     const long long nq = (long long)g.Cq * g.N, nk = nq / 2, nv = (long long)g.C * g.N / 2;
-    const int Ah = g.A / 2;
-    T* dst = dqkv + ((size_t)b * g.N + tok) * ldq;
-    if (cc < g.Cq) {
-        stf(dst + cc, dQf[b * nq + (((long long)cc * g.A + d0) * g.D1 + d1) * g.D2 + d2]);
-        return;
+    for (int idx = tid; idx < 2 * g.Cq * TP; idx += 256) {
+        const int p = idx % TP, r = idx / TP, c = r % g.Cq, s2 = r / g.Cq;
+        tile[(s2 * TP + p) * NCP + c] = p0 + p < PL ? dQf[b * nq + ((long long)c * g.A + 2 * dp + s2) * PL + p0 + p] : 0.f;
     }
-    cc -= g.Cq;
-    const bool isv = cc >= g.Cq;
-    if (isv) cc -= g.Cq;
-    const long long pe = (((long long)cc * Ah + (d0 >> 1)) * g.D1 + d1) * g.D2 + d2;
-    const bool mine = (isv ? vsel[b * nv + pe] : ksel[b * nk + pe]) == (d0 & 1);
-    const float gr = mine ? (isv ? dVp[b * nv + pe] : dKp[b * nk + pe]) : 0.f;
-    stf(dst + (isv ? voff : koff) + cc, gr);
+    for (int idx = tid; idx < (g.Cq + g.C) * TP; idx += 256) {
+        const int p = idx % TP, c = idx / TP;
+        float gr = 0.f; int sel = 0;
+        if (p0 + p < PL) {
+            if (c < g.Cq) { const long long e = ((long long)c * Ah + dp) * PL + p0 + p; gr = dKp[b * nk + e]; sel = ksel[b * nk + e]; }
+            else { const long long e = ((long long)(c - g.Cq) * Ah + dp) * PL + p0 + p; gr = dVp[b * nv + e]; sel = vsel[b * nv + e]; }
+        }
+        tile[p * NCP + g.Cq + c] = sel == 0 ? gr : 0.f;
+        tile[(TP + p) * NCP + g.Cq + c] = sel == 1 ? gr : 0.f;
+    }
+    __syncthreads();
+    T* base = dqkv + (size_t)b * g.N * ldq;
+    for (int idx = tid; idx < 2 * TP * NC; idx += 256) {
+        const int col = idx % NC, rp = idx / NC, p = rp % TP, s2 = rp / TP;
+        if (p0 + p >= PL) continue;
+        const int pos = p0 + p, d1 = pos / g.D2, d2 = pos - d1 * g.D2;
+        const int dst = col < g.Cq ? col : col < 2 * g.Cq ? koff + col - g.Cq : voff + col - 2 * g.Cq;
+        stf(base + (size_t)token(g, 2 * dp + s2, d1, d2) * ldq + dst, tile[(s2 * TP + p) * NCP + col]);
+    }
 }
 
 }  // namespace
@@ -339,8 +391,19 @@ extern "C" int dvd_sepattn_forward(int dtype, const void* qkv, int ldq, int Cq, 
     if (rc != DVD_OK) return rc;
     const SepGeo g = make_geo(T, W, H, axis, C, Cq);
     const long long per = (long long)Cq * g.N * 3 / 2 + (long long)C * g.N / 2;
-    BY_DTYPE(dtype, sep_gather_kernel<T><<<cdiv(B * per, 256), 256, 0, S_>>>(g, (const T*)qkv, ldq, koff, voff, Qf, Kp, Vp,
-                                                                             ksel, vsel, B));
+    const int PL = g.D1 * g.D2, NC = 2 * Cq + C;
+    if ((size_t)2 * 8 * (NC + 1) * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    // positions per tile: as many as 64 KB of LDS hold (two attended coordinates x TP rows of NC + 1 floats)
+#define SEP_TILED(KERNEL, ...)                                                                                                         \
+    do {                                                                                                                               \
+        if ((size_t)2 * 32 * (NC + 1) * sizeof(float) <= 64 * 1024)                                                                    \
+            BY_DTYPE(dtype, KERNEL<T, 32><<<dim3(cdiv(PL, 32), g.A / 2, (unsigned)B), 256, (size_t)2 * 32 * (NC + 1) * sizeof(float), S_>>>(__VA_ARGS__));   \
+        else if ((size_t)2 * 16 * (NC + 1) * sizeof(float) <= 64 * 1024)                                                               \
+            BY_DTYPE(dtype, KERNEL<T, 16><<<dim3(cdiv(PL, 16), g.A / 2, (unsigned)B), 256, (size_t)2 * 16 * (NC + 1) * sizeof(float), S_>>>(__VA_ARGS__));   \
+        else                                                                                                                           \
+            BY_DTYPE(dtype, KERNEL<T, 8><<<dim3(cdiv(PL, 8), g.A / 2, (unsigned)B), 256, (size_t)2 * 8 * (NC + 1) * sizeof(float), S_>>>(__VA_ARGS__));      \
+    } while (0)
+    SEP_TILED(sep_gather_kernel, g, (const T*)qkv, ldq, koff, voff, Qf, Kp, Vp, ksel, vsel);
     // the partial score sums live in `y` until sep_out_kernel writes it (B * 8 * A * A/2 floats; y holds B * N * ldx elements)
     float* part = reinterpret_cast<float*>(y);
     if ((long long)kSepSplit * g.A * (g.A / 2) * 4 > g.N * ldx * (dtype == DVD_BF16 ? 2 : 4)) return DVD_E_SHAPE;       // (never: N >= 8 A)
@@ -348,7 +411,11 @@ extern "C" int dvd_sepattn_forward(int dtype, const void* qkv, int ldq, int Cq, 
     sep_softmax_kernel<<<dim3(g.A, (unsigned)B), 64, 0, S_>>>(part, att, g.A, g.A / 2);
     if (ldx != C &&      // padded channel columns of y must read zero afterwards (sep_out_kernel writes the real ones only)
         hipMemsetAsync(y, 0, (size_t)B * kSepSplit * g.A * (g.A / 2) * sizeof(float), S_) != hipSuccess) return DVD_E_LAUNCH;
-    BY_DTYPE(dtype, sep_out_kernel<T><<<cdiv(B * C * g.N, 256), 256, 0, S_>>>(g, Vp, att, (const T*)x, ldx, gamma, (T*)y, B));
+    {
+        const int QT = g.A <= 16 ? 8 : g.A <= 48 ? 4 : 2;
+        const dim3 grid(cdiv(g.N / g.A, QT), cdiv(C, 32), (unsigned)B);
+        BY_DTYPE(dtype, sep_outio_kernel<T, false><<<grid, 256, 0, S_>>>(g, Vp, att, (const T*)x, ldx, gamma, (T*)y, nullptr, nullptr));
+    }
     return launch_status();
 }
 
@@ -364,14 +431,19 @@ extern "C" int dvd_sepattn_backward(int dtype, const void* dy, int ldx, int C, i
     if (rc != DVD_OK) return rc;
     const SepGeo g = make_geo(T, W, H, axis, C, Cq);
     const long long per = (long long)Cq * g.N * 3 / 2 + (long long)C * g.N / 2;
-    BY_DTYPE(dtype, sep_dout_kernel<T><<<cdiv(B * C * g.N, 256), 256, 0, S_>>>(g, Vp, att, (const T*)dy, ldx, gamma, dO,
-                                                                               dgamma, B));
+    {
+        const int QT = g.A <= 16 ? 8 : g.A <= 48 ? 4 : 2;
+        const dim3 grid(cdiv(g.N / g.A, QT), cdiv(C, 32), (unsigned)B);
+        BY_DTYPE(dtype, sep_outio_kernel<T, true><<<grid, 256, 0, S_>>>(g, Vp, att, (const T*)dy, ldx, gamma, (T*)nullptr, dO, dgamma));
+    }
     // the partial sums of datt live in dQf until sep_dops_kernel writes it (B * 8 * A * A/2 of its B * Cq * N floats)
     if ((long long)kSepSplit * g.A * (g.A / 2) > (long long)Cq * g.N) return DVD_E_SHAPE;
     sep_prod_kernel<false><<<dim3(kSepSplit, (unsigned)B), 1024, 0, S_>>>(dO, Vp, dQf, g.A, g.A / 2, (long long)C * g.D1 * g.D2);
     sep_dsoft_kernel<<<dim3(g.A, (unsigned)B), 64, 0, S_>>>(dQf, att, dS, g.A, g.A / 2);
-    sep_dops_kernel<<<cdiv(B * per, 256), 256, 0, S_>>>(g, dO, att, dS, Qf, Kp, dQf, dKp, dVp, B);
-    BY_DTYPE(dtype, sep_scatter_kernel<T><<<cdiv(B * g.N * (2 * Cq + C), 256), 256, 0, S_>>>(
-                        g, dQf, dKp, dVp, ksel, vsel, (T*)dqkv, ldq, koff, voff, B));
+    sep_dqk_kernel<<<dim3(cdiv((long long)Cq * g.N / g.A, 256), (unsigned)B), 256, 0, S_>>>(g, dS, Qf, Kp, dQf, dKp);
+    sep_dv_kernel<<<dim3(cdiv((long long)C * g.N / g.A, 256), (unsigned)B), 256, 0, S_>>>(g, dO, att, dVp);
+    const int PL = g.D1 * g.D2, NC = 2 * Cq + C;
+    if ((size_t)2 * 8 * (NC + 1) * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    SEP_TILED(sep_scatter_kernel, g, dQf, dKp, dVp, ksel, vsel, (T*)dqkv, ldq, koff, voff);
     return launch_status();
 }
