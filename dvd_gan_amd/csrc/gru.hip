@@ -441,7 +441,7 @@ constexpr int kMaxMember = 2 * DVD_GRU_STACK_MAX;
 int stack_kind(const dvd_gru_stack_desc* s) {
     const dvd_gru_desc& a = s->layer[0];
     if (a.H != a.W || ilog2_exact(a.H) < 0) return -1;
-    if (a.H >= 16) return 0;
+    if (a.H >= 16) return 0;                         // (128 x 128 tiles, three workgroups per CU: 4-8 % slower on the 16 x 16 / 32 x 32 stages)
     if (a.H == 4) return 4;
     if (a.H != 8) return -1;
     long long t256 = 0;                              // tiles of the U group on 256-row tiles
