@@ -46,12 +46,17 @@ template <int TM, int WN, int WMV, bool UP2> struct HaloGbCfg {
 template <int TM, bool RELU, class LdA, class Next>
 __device__ __forceinline__ void gb_step(f32x16 (&acc)[TM][2], const bf16x8 (&b)[2][2], LdA ldA, Next next) {
     constexpr int NU = 2 * TM;
+#ifndef DVD_GB_ADEPTH
+#define DVD_GB_ADEPTH 2
+#endif
+    constexpr int AD = DVD_GB_ADEPTH;                 // A fragments requested this many units ahead
     bf16x8 a[NU];
-    a[0] = ldA(0); a[1] = ldA(1);
+#pragma unroll
+    for (int u = 0; u < AD && u < NU; ++u) a[u] = ldA(u);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        if (u + 2 < NU) a[u + 2] = ldA(u + 2);
+        if (u + AD < NU) a[u + AD] = ldA(u + AD);
         const int kk = u / TM, tm = u % TM;
         if constexpr (RELU) a[u] = __builtin_bit_cast(bf16x8, relu16_bf16(__builtin_bit_cast(u32x4, a[u])));
 #pragma unroll

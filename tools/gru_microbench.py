@@ -94,6 +94,34 @@ def pairs(iters, B, T):
             print(f"{LAYERS[a][0]} + {LAYERS[b][0]} {fn_name[19:]:9s}: sequential {ts:7.2f} ms   concurrent {tc:7.2f} ms   ({100 * (1 - tc / ts):4.1f} % saved)", flush=True)
 
 
+def triples(iters, B, T):
+    """The three layers of each ConvGRU as three INDEPENDENT recurrences (own random gx) on three streams vs one after the other:
+    an upper bound of what per-layer streams (instead of grouped launches) could overlap."""
+    dev, dt = "cuda", torch.bfloat16
+    lib = L.lib()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for gi in range(4):
+        ds = [setup(*LAYERS[3 * gi + l], B, T, dev, dt, lib) for l in range(3)]
+
+        def run(fn_name, concurrent):
+            fn = getattr(lib, fn_name)
+            cur = torch.cuda.current_stream()
+            if not concurrent:
+                for d_, _ in ds:
+                    L.check(fn(C.byref(d_), C.c_void_p(cur.cuda_stream)))
+                return
+            for st_ in streams:
+                st_.wait_stream(cur)
+            for (d_, _), st_ in zip(ds, streams):
+                L.check(fn(C.byref(d_), C.c_void_p(st_.cuda_stream)))
+            for st_ in streams:
+                cur.wait_stream(st_)
+        for fn_name in ("dvd_convgru_layer_forward", "dvd_convgru_layer_backward"):
+            ts = timed(lambda: run(fn_name, False), iters)
+            tc = timed(lambda: run(fn_name, True), iters)
+            print(f"gru{gi} {fn_name[19:]:9s}: three layers sequential {ts:7.2f} ms   on three streams {tc:7.2f} ms   ({100 * (1 - tc / ts):4.1f} % saved)", flush=True)
+
+
 def halves(iters, B, T):
     """One layer at batch B on one stream vs the two halves of the batch (independent recurrences) on two streams."""
     dev, dt = "cuda", torch.bfloat16
@@ -214,6 +242,8 @@ def main():
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
         sel = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(LAYERS))
         return parts(3, 64, 48, n, sel)
+    if len(sys.argv) > 1 and sys.argv[1] == "triples":
+        return triples(3, 64, 48)
     if len(sys.argv) > 1 and sys.argv[1] == "pairs":
         return pairs(3, 64, 48)
     if len(sys.argv) > 1 and sys.argv[1] == "halves":
