@@ -98,7 +98,8 @@ template <> __device__ __forceinline__ float gate_tanh<bf16_t>(float x) {
     return copysignf(r, x);
 }
 
-// Internal (not part of the public ABI): ConvGRU gate math fused into the convolution epilogue, used
+// Internal (not part of the public ABI; hidden visibility: the library exports exactly what include/dvdgan_hip.h declares):
+// ConvGRU gate math fused into the convolution epilogue, used
 // by gru.hip when the recurrent conv needs no split-K.  mode 1: [u|r] conv, mode 2: out-gate conv (forward);
 // mode 3: d(h*r) conv of the backward pass (r, hprev, h32n = fp32 carry, o = dg base), mode 4: carry += conv,
 // mode 5: mode 4 + first half of the next BPTT step (gx = dh_out, u_in = u, hr = o-gate, hprev, o = dg of that step).
@@ -110,10 +111,10 @@ struct GruEpi {
     void* u; void* r; void* hr; void* o; void* hn; float* h32n;
     float* slabs; unsigned* tickets;
 };
-extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream);
 // Internal: n independent convolutions (d[i], gate epilogue g[i], mode 0 = none / 6 = direct epilogue behind the in-launch split-K
 // combine) in ONE launch of kernel `kind`; see conv_igemm.hip
-extern "C" int dvd_conv_forward_group(const dvd_conv_desc* d, const GruEpi* g, int n, int kind, int run, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int dvd_conv_forward_group(const dvd_conv_desc* d, const GruEpi* g, int n, int kind, int run, void* stream);
 // Internal: weight gradients with 3 (8) channels on one side and 64 on the other (wgrad_thin.hip); 0 floats = not served there
 long long dvd_wgrad_thin_ws_floats(const dvd_wgrad_desc* d);
 int dvd_wgrad_thin(const dvd_wgrad_desc* d, void* stream);

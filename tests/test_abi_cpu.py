@@ -27,6 +27,13 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert lib.dvd_abi_version() == L.ABI_VERSION
     assert b"unsupported shape" in lib.dvd_strerror(-2)
+    # ... and nothing else: the internal cross-file entry points (common.h) have hidden visibility
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH]).decode()
+        exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("dvd_"))
+        assert exported == names, sorted(set(exported) ^ set(names))
 
 
 def test_descriptor_layouts_match_the_library():
