@@ -684,14 +684,26 @@ __global__ __launch_bounds__(1024) void wgrad_row_bias_reduce_kernel(WgBiasRedK 
     }
 }
 
-// bias gradient of the one-tap kernel's workspace path: dbias[co] += sum over the row slices, in slice order
-__global__ void wgrad_bias_reduce_kernel(const float* wsb, float* dbias, int nslice, int tiles_co, int BMc, int Cout) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= Cout) return;
-    const int tco = co / BMc, c = co - tco * BMc;
+// bias gradient of the one-tap kernel's workspace path: dbias[co] += sum over the row slices.  Block = 64 channels x 16 slice lanes:
+// lane q sums slices q, q+16, ... in order, the sixteen lane sums are added in lane order (one thread per channel walking up to
+// 768 slices took 48 us per call, 1.9 ms per step).
+__global__ __launch_bounds__(1024) void wgrad_bias_reduce_kernel(const float* wsb, float* dbias, int nslice, int tiles_co, int BMc, int Cout) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6, co = blockIdx.x * 64 + col;
     float a = 0.f;
-    for (int z = 0; z < nslice; ++z) a += wsb[((size_t)z * tiles_co + tco) * BMc + c];
-    dbias[co] += a;
+    if (co < Cout) {
+        const int tco = co / BMc, c = co - tco * BMc;
+#pragma unroll 4
+        for (int z = q; z < nslice; z += 16) a += wsb[((size_t)z * tiles_co + tco) * BMc + c];
+    }
+    red[q][col] = a;
+    __syncthreads();
+    if (q == 0 && co < Cout) {
+        float t = red[0][col];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t += red[i][col];
+        dbias[co] += t;
+    }
 }
 
 // Second phase of the workspace path: dw[co][ci][tap] += sum over row slices of the partial tiles.
@@ -776,7 +788,13 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         constexpr long long tgt_row = 512;
         const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps);
         msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
-        const long long cap = M / minrows > 0 ? M / minrows : 1;
+        long long cap = M / minrows > 0 ? M / minrows : 1;
+        if (ntaps == 1 && cap * base < 256) {
+            // short 1 x 1 layers (shortcut and attention projections on <= 16-pixel maps): 16 workgroups of 4096 rows each took
+            // 110-150 us for 4 GFLOP -- slices down to 256 rows until every CU has a workgroup (round 5)
+            const long long want = (256 + base - 1) / base, cap2 = M / 256;
+            cap = cap2 < want ? (cap2 > cap ? cap2 : cap) : want;
+        }
         if (msplit > cap) msplit = cap;
         // whole rounds: the workgroups run `conc` at a time (register / LDS limited); a grid a few workgroups over a
         // multiple of that pays a full extra round (20 x 103 = 2060 workgroups = 8.05 rounds of 256 -> 9 rounds)
@@ -874,7 +892,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
                  p.Cin_real, p.s_co, p.s_ci, p.s_tap, overwrite};
         const long long n = (long long)grid.x * r.BMc * r.BNc;
         wgrad_reduce_kernel<<<cdiv(n / 4, 256), 256, 0, st>>>(r);
-        if (p.dbias) wgrad_bias_reduce_kernel<<<cdiv(p.Cout, 256), 256, 0, st>>>(p.wsb, p.dbias, (int)msplit, p.tiles_co, ta * 64, p.Cout);
+        if (p.dbias) wgrad_bias_reduce_kernel<<<cdiv(p.Cout, 64), 1024, 0, st>>>(p.wsb, p.dbias, (int)msplit, p.tiles_co, ta * 64, p.Cout);
     }
     return launch_status();
 }
