@@ -663,6 +663,16 @@ def test_separable_attention_generator_shape_vs_oracle():
         xr = x.clone().requires_grad_(True)
         want = O.separable_attn(sd, "", xr)
         want.backward(gy)
+        if shape[1] == 32:      # bf16 storage through the same (8-channel-wide) kernels: loose bounds, same oracle
+            import copy
+            ab = copy.deepcopy(at).to(DEV)
+            for m in ab.model:
+                m.compute_dtype = torch.bfloat16
+            xb = x.to(DEV).requires_grad_(True)
+            gb = ab(xb)
+            assert rel(gb, want.detach()) < 1e-2, shape
+            gb.backward(gy.to(DEV))
+            assert rel(xb.grad, xr.grad) < 8e-2, (shape, rel(xb.grad, xr.grad))    # 4.1e-2: softmax over scores that are sums of 6144 bf16-rounded products
         at = at.to(DEV)
         xg = x.to(DEV).requires_grad_(True)
         got = at(xg)
