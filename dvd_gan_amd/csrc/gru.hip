@@ -15,7 +15,14 @@
 // Backward walks t = T-1..0 with two backward-data convs per step; every weight gradient and the
 // x-path gradient are batched over all T by the caller afterwards (dg holds d(pre-activation)).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <vector>
 
 namespace {
 
@@ -432,6 +439,9 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
 //             step t (all three gate gradients of the step are complete), whose result is layer l-1's dh_out of step t -- needed by
 //             layer l-1's B convolution of step t + 1 in pair k + 1.
 // The steps without a previous state (t = 0, no h0) and the first BPTT step of a layer run the elementwise gate kernels.
+#ifndef DVD_STACK_SEARCH_KINDS
+#define DVD_STACK_SEARCH_KINDS(kind) 1
+#endif
 namespace {
 
 struct Member { dvd_conv_desc d; long long tiles; int kchunks; int gate; };
@@ -487,6 +497,84 @@ void member_conv(Member& m, const dvd_gru_desc& L, const void* in, int C, int ld
     m.kchunks = (C + 31) / 32;
 }
 
+// ---- split-K factors of a grouped launch: a search over per-member factors against a model of the launch.
+// The members of a group differ 5x in K length (3 x 3 on 256 channels beside 5 x 5 on 768): one factor for all of them -- the
+// first round-5 policy, "fill 512 workgroups" -- splits short tiles for nothing and leaves the long tiles of the 5 x 5 layer as
+// the launch's makespan.  Model: an XCD runs its share of the workgroups on `slots` concurrent slots in the
+// order group_dispatch issues them (members by decreasing length); a workgroup costs its K steps plus a fixed prologue / epilogue
+// (in K steps), a split tile a little more (slab traffic, the combine by its last workgroup).  Plans are cached per signature.
+struct SplitPlan { int ns[2 * DVD_GRU_STACK_MAX]; };
+double model_makespan(int n, const long long* tiles, const int* units, const int* ns, int slots, double fixed, double split_cost) {
+    int order[2 * DVD_GRU_STACK_MAX];
+    double len[2 * DVD_GRU_STACK_MAX];
+    for (int i = 0; i < n; ++i) { order[i] = i; len[i] = (double)units[i] / ns[i] + fixed + (ns[i] > 1 ? split_cost : 0.0); }
+    std::sort(order, order + n, [&](int a, int b) { return (double)units[a] / ns[a] > (double)units[b] / ns[b]; });
+    std::priority_queue<double, std::vector<double>, std::greater<double>> q;
+    for (int i = 0; i < slots; ++i) q.push(0.0);
+    double end = 0.0;
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi];
+        const long long w = (tiles[i] * ns[i] + 7) / 8;              // this XCD's workgroups of member i
+        for (long long k = 0; k < w; ++k) {
+            const double t = q.top() + len[i];
+            q.pop(); q.push(t);
+            if (t > end) end = t;
+        }
+    }
+    return end;
+}
+SplitPlan plan_splits(int kind, bool backward, int n, const Member* m, long long cap) {
+    static std::map<std::string, SplitPlan> cache;
+    static std::mutex mu;
+    long long tiles[2 * DVD_GRU_STACK_MAX]; int units[2 * DVD_GRU_STACK_MAX], capi[2 * DVD_GRU_STACK_MAX];
+    std::string key;
+    key.append((const char*)&kind, sizeof kind); key.push_back(backward ? 1 : 0);
+    for (int i = 0; i < n; ++i) {
+        tiles[i] = m[i].tiles; units[i] = m[i].kchunks * m[i].d.kh * m[i].d.kw;
+        capi[i] = (int)std::min<long long>(cap, m[i].kchunks);
+        if (m[i].tiles > 1024) capi[i] = 1;                               // one ticket per tile, 1024 tickets per member
+        key.append((const char*)&tiles[i], sizeof tiles[i]); key.append((const char*)&units[i], sizeof units[i]);
+        key.append((const char*)&capi[i], sizeof capi[i]);
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const int slots = (kind == 0 || kind == 2) ? 64 : 96;
+    // fitted on tools/gru_microbench.py stack (B = 64; K steps of the launch's tile shape): a split tile is cheap on 4 x 4 frames
+    // (64 KB slabs, few tiles) and dear on 256-row tiles (128 KB slabs; the tile's last workgroup combines, then runs the epilogue):
+    // 8 x 8 forward 13.85 -> 12.87 ms with only the 5 x 5 layer split, 4 x 4 5.39 / 6.09 -> 5.03 / 5.56, 16 x 16 backward 46.1 -> 45.0
+    double fixed = (kind == 0 || kind == 2) ? 12.0 : 16.0;
+    double split_cost = kind == 4 ? 3.0 : kind == 0 ? 150.0 : backward ? 50.0 : 80.0;
+#ifdef DVD_STACK_SEARCH_DEBUG
+    if (const char* e = getenv("DVD_SS_FIXED")) fixed = atof(e);
+    if (const char* e = getenv("DVD_SS_SPLIT")) split_cost = atof(e);
+#endif
+    static const int opts[] = {1, 2, 3, 4, 8};
+    SplitPlan best{}; double best_t = 1e30;
+    int idx[2 * DVD_GRU_STACK_MAX] = {0};
+    for (;;) {
+        int ns[2 * DVD_GRU_STACK_MAX]; bool ok = true; int nsplit_members = 0;
+        for (int i = 0; i < n; ++i) { ns[i] = opts[idx[i]]; if (ns[i] > capi[i]) ok = false; nsplit_members += ns[i] > 1; }
+        if (ok) {
+            const double t = model_makespan(n, tiles, units, ns, slots, fixed, split_cost) * (1.0 + 0.004 * nsplit_members);
+            if (t < best_t) { best_t = t; for (int i = 0; i < n; ++i) best.ns[i] = ns[i]; }
+        }
+        int j = 0;
+        while (j < n && ++idx[j] == (int)(sizeof opts / sizeof opts[0])) idx[j++] = 0;
+        if (j == n) break;
+    }
+#ifdef DVD_STACK_SEARCH_DEBUG
+    {
+        int one[2 * DVD_GRU_STACK_MAX]; for (int i = 0; i < n; ++i) one[i] = 1;
+        fprintf(stderr, "plan kind %d %s:", kind, backward ? "bwd" : "fwd");
+        for (int i = 0; i < n; ++i) fprintf(stderr, " [tiles %lld units %d cap %d -> ns %d]", tiles[i], units[i], capi[i], best.ns[i]);
+        fprintf(stderr, "  model %.0f (unsplit %.0f)\n", best_t, model_makespan(n, tiles, units, one, slots, fixed, split_cost));
+    }
+#endif
+    cache[key] = best;
+    return best;
+}
+
 // Split-K factors of one grouped launch and the slab space behind them; launches unless `dry`.
 int run_group(const dvd_gru_stack_desc* s, int kind, Member* m, GruEpi* g, int n, void* stream, bool dry, long long& ws_need, bool backward) {
     if (n == 0) return DVD_OK;
@@ -498,10 +586,16 @@ int run_group(const dvd_gru_stack_desc* s, int kind, Member* m, GruEpi* g, int n
     const long long target = (kind == 0 || kind == 2) ? 512 : 768;
     long long want = (target + total - 1) / total;
     if (want > cap) want = cap;
+    SplitPlan plan{};
+    bool searched = !s->layer_policy && DVD_STACK_SEARCH_KINDS(kind);
+#ifdef DVD_STACK_SEARCH_DEBUG
+    if (const char* e = getenv("DVD_SS_MASK")) searched = searched && ((atoi(e) >> kind) & 1) && ((atoi(e) >> (backward ? 9 : 8)) & 1);
+#endif
+    if (searched) plan = plan_splits(kind, backward, n, m, cap);
     long long cursor = 0;
     dvd_conv_desc d[kMaxMember];
     for (int i = 0; i < n; ++i) {
-        long long ns = want;
+        long long ns = searched ? plan.ns[i] : want;
         if (s->layer_policy)
             ns = m[i].gate ? dvd_conv_pick_nsplit(DVD_BF16, (long long)m[i].d.frames * m[i].d.H * m[i].d.W, m[i].d.Cout, m[i].d.C,
                                                   m[i].d.kh * m[i].d.kw) : 1;
@@ -543,7 +637,7 @@ int stack_forward(const dvd_gru_stack_desc* s, void* stream, bool dry, long long
                 const float* h32p = (d.h32 && t > 0) ? d.h32 + (size_t)(t & 1) * M * h : nullptr;
                 float* h32n = d.h32 ? d.h32 + (size_t)((t + 1) & 1) * M * h : nullptr;
                 const unsigned grid = cdiv(M * (h / 8), 256);
-                const bool has_prev = dry || t > 0 || d.h0 != nullptr;      // (dry: workspace sizing, assume the larger schedule)
+                const bool has_prev = t > 0 || d.h0 != nullptr;             // (the dry run sizes the workspace for exactly this schedule)
                 if (!has_prev) {                                  // step 0 without a supplied state: gates of the x-part alone
                     if (dry) continue;
                     using T_ = bf16_t;
@@ -637,7 +731,7 @@ int stack_backward(const dvd_gru_stack_desc* s, void* stream, bool dry, long lon
                 const char* o = (const char*)d.o_all + t * step;
                 char* dg = (char*)d.dg + (size_t)t * M * 3 * h * esz;
                 const unsigned grid = cdiv(M * (h / 8), 256);
-                const bool has_prev = dry || t > 0 || d.h0 != nullptr;
+                const bool has_prev = t > 0 || d.h0 != nullptr;
                 if (phase == 0) {
                     if (t == T - 1 && !dry)                       // first BPTT step of the layer: nothing upstream to ride on
                         gru_bwd_out_kernel<T_><<<grid, 256, 0, S_>>>((const T_*)dh_of(l, t), d.carry, nullptr, 0, (const T_*)u, (const T_*)o,

@@ -88,7 +88,15 @@ def test_wavefront_equals_layer_by_layer_bitwise(case, monkeypatch):
         assert _rel(a, b) < 1e-5, (k, _rel(a, b))               # same kernels on bit-equal operands; fp32 atomics in the narrow layers
 
 
-@pytest.mark.parametrize("case", CASES[:7:2], ids=lambda c: f"T{c[0]}B{c[1]}S{c[2]}")
+WIDE = [    # layers wide enough for the production split-K policy to split members of a grouped launch (x-part convolutions included)
+    (3, 2, 16, 32, [64, 128, 64], [3, 5, 5], False, None, 0),
+    (3, 1, 32, 32, [64, 128, 64], [3, 5, 5], False, (True, False, True), 0),
+    (3, 4, 8, 64, [128, 256, 128], [3, 5, 3], False, None, 0),
+    (3, 8, 4, 64, [128, 256, 128], [3, 5, 3], True, None, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES[:7:2] + WIDE, ids=lambda c: f"T{c[0]}B{c[1]}S{c[2]}h{c[4][0]}")
 def test_wavefront_production_policy_and_outer_gradients(case, monkeypatch):
     """Split-K factors chosen per grouped launch, and a loss on EVERY layer's states (the gradient from outside the stack rides
     in the epilogue of the x-part backward-data convolution, in fp32, where autograd adds two bf16 tensors)."""
