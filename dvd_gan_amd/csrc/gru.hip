@@ -610,8 +610,11 @@ int run_group(const dvd_gru_stack_desc* s, int kind, Member* m, GruEpi* g, int n
         }
         d[i] = m[i].d;
     }
-    if (cursor > ws_need) ws_need = cursor;
-    if (dry) return DVD_OK;
+    if (dry) {
+        if (cursor > ws_need) ws_need = cursor;
+        return DVD_OK;
+    }
+    if (cursor > ws_need) return DVD_E_SHAPE;      // (cannot happen: the launch walks the schedule the sizing query walked -- but a slab overrun is a memory fault)
     return dvd_conv_forward_group(d, g, n, kind, s->run, stream);
 }
 
@@ -812,12 +815,12 @@ extern "C" long long dvd_convgru_stack_ws_floats(const dvd_gru_stack_desc* d) {
 extern "C" int dvd_convgru_stack_forward(const dvd_gru_stack_desc* d, void* stream) {
     const int rc = stack_check(d, false);
     if (rc) return rc;
-    long long need = 0;
+    long long need = dvd_convgru_stack_ws_floats(d);      // what the caller was told to allocate: the launch refuses to go past it
     return stack_forward(d, stream, false, need);
 }
 extern "C" int dvd_convgru_stack_backward(const dvd_gru_stack_desc* d, void* stream) {
     const int rc = stack_check(d, true);
     if (rc) return rc;
-    long long need = 0;
+    long long need = dvd_convgru_stack_ws_floats(d);
     return stack_backward(d, stream, false, need);
 }
