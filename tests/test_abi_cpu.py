@@ -206,4 +206,14 @@ def test_convgru_stack_queries_need_no_gpu():
     assert lib.dvd_convgru_stack_ws_floats(C.byref(g3)) >= 1       # one-round groups at 32 x 32: nothing is split
     small = lib.dvd_convgru_stack_ws_floats(C.byref(stack(4, [256, 512, 256], [3, 5, 3])))
     assert small > 16384 and small % 16384 == 0                    # 4 x 4 frames: split-K slabs of whole 128 x 128 tiles
+    # the sizing query walks exactly the schedule of the launch: repeatable, and a supplied initial state (more members in the
+    # pipeline-fill groups) changes the plan without ever yielding less than one float
+    for S in (4, 8, 16):
+        sd = stack(S, [256, 512, 256], [3, 5, 3])
+        a = lib.dvd_convgru_stack_ws_floats(C.byref(sd))
+        assert a == lib.dvd_convgru_stack_ws_floats(C.byref(sd)) and a >= 1
+        for l in range(3):
+            sd.layer[l].h0 = 1
+        b = lib.dvd_convgru_stack_ws_floats(C.byref(sd))
+        assert b >= 1 and b % 16384 == 0
     assert lib.dvd_convgru_stack_forward(C.byref(stack(12, [256], [3])), None) == -2
