@@ -64,6 +64,9 @@ def parse():
                          "latent clip after the first ConvGRU / :8-111 SeparableAttn after module 8); off in the reference and in BASELINE's configs")
     ap.add_argument("--dp-mode", default="replica", choices=["replica", "global"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N=1 only: create a ONE-rank RCCL group and run the whole data-parallel exchange (all-reduces on the exchange "
+                         "stream, bucket hooks, side-stream fences) -- prices the exchange's fences / host work at this batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-prof", action="store_true")
     return ap.parse_args()
@@ -144,6 +147,8 @@ def carried_states(a, batch, dev):
 
 def main():
     a = parse()
+    if a.force_exchange:
+        os.environ["DVD_FORCE_EXCHANGE"] = "1"
     respawn_if_needed(a)
     from dvd_gan_amd import dist as D
     from dvd_gan_amd import lib as L
@@ -284,7 +289,8 @@ def main():
                                       + (", initial ConvGRU states supplied and differentiated" if a.state_carry else "")
                                       + (f", generator attention blocks ON ({a.g_attn}; not part of BASELINE's configs)" if a.g_attn != "none" else "")
                                       + f" (BASELINE configs[{cfg_id}])",
-                          "global_batch": gB, "parallelism": f"dp{world}" + ("" if world == 1 else f" ({a.dp_mode} batch norm)")},
+                          "global_batch": gB, "parallelism": f"dp{world}" + ("" if world == 1 else f" ({a.dp_mode} batch norm)")
+                          + (f" + forced one-rank RCCL exchange ({a.dp_mode} batch norm)" if a.force_exchange else "")},
                "losses": [round(v, 4) for v in lossv],
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
         if roof:
@@ -292,7 +298,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

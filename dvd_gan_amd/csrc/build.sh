@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 JOBS=${JOBS:-6}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value"
 mkdir -p build
 pids=()
 for f in *.hip; do

@@ -16,6 +16,7 @@
 // x-path gradient are batched over all T by the caller afterwards (dg holds d(pre-activation)).
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -445,6 +446,8 @@ extern "C" int dvd_convgru_layer_backward(const dvd_gru_desc* d, void* stream) {
 namespace {
 
 struct Member { dvd_conv_desc d; long long tiles; int kchunks; int gate; };
+// debug bookkeeping behind dvd_debug_stack_ws (tests only): the last sizing answer and the largest slab cursor a LAUNCHED group used
+std::atomic<long long> g_ws_sized{0}, g_ws_high{0};
 constexpr int kMaxMember = 2 * DVD_GRU_STACK_MAX;
 
 // kernel family serving a stack: 0 = frames >= 16 pixels (256 x 128 tiles), 2 / 3 = 8 x 8 frames (256- / 128-row tiles), 4 = 4 x 4
@@ -614,6 +617,7 @@ int run_group(const dvd_gru_stack_desc* s, int kind, Member* m, GruEpi* g, int n
         if (cursor > ws_need) ws_need = cursor;
         return DVD_OK;
     }
+    for (long long seen = g_ws_high.load(); cursor > seen && !g_ws_high.compare_exchange_weak(seen, cursor);) {}
     if (cursor > ws_need) return DVD_E_SHAPE;      // (cannot happen: the launch walks the schedule the sizing query walked -- but a slab overrun is a memory fault)
     return dvd_conv_forward_group(d, g, n, kind, s->run, stream);
 }
@@ -810,7 +814,14 @@ extern "C" long long dvd_convgru_stack_ws_floats(const dvd_gru_stack_desc* d) {
     stack_forward(d, nullptr, true, need);
     stack_backward(d, nullptr, true, nb);
     if (nb > need) need = nb;
+    g_ws_sized.store(need);
     return need > 0 ? need : 1;
+}
+// Test hook: out[0] = floats the last dvd_convgru_stack_ws_floats call asked for (0 = no member of any group is split),
+// out[1] = the largest slab cursor any grouped launch has used since the last reset.  reset != 0 clears out[1] afterwards.
+extern "C" void dvd_debug_stack_ws(long long* out, int reset) {
+    if (out) { out[0] = g_ws_sized.load(); out[1] = g_ws_high.load(); }
+    if (reset) g_ws_high.store(0);
 }
 extern "C" int dvd_convgru_stack_forward(const dvd_gru_stack_desc* d, void* stream) {
     const int rc = stack_check(d, false);

@@ -35,7 +35,7 @@ def init_from_env(backend=None):
             raise RuntimeError(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
         torch.cuda.set_device(local)
     backend = backend or os.environ.get("DVD_DIST_BACKEND")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if use_cuda else "gloo")
@@ -66,6 +66,20 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def forced():
+    """DVD_FORCE_EXCHANGE=1 (test / measurement switch): run the whole data-parallel machinery -- process group, rank-0
+    broadcast, shared seed, gradient all-reduces on the exchange stream, the generator's bucket hooks and their side-stream
+    fences, cross-replica sums in "global" mode -- even when the world is ONE rank.  A one-rank RCCL group executes every
+    collective except the transport, so `tests/test_gpu_dist.py` can hold the nccl branch bit-equal to the plain step on a
+    single GPU, and `bench.py --force-exchange` prices the exchange's host / fence overhead at B=64."""
+    return os.environ.get("DVD_FORCE_EXCHANGE", "0") == "1"
+
+
+def exchange_on():
+    """True when gradients (and, in "global" mode, batch statistics / condition rows) go through torch.distributed."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def collective_device():
     """Device a tensor must live on to take part in a collective of the default group."""
     if dist.is_initialized() and dist.get_backend() == "nccl":
@@ -94,8 +108,9 @@ class GradExchange:
 
     def __init__(self):
         self.world = world_size()
+        self.active = exchange_on()           # world > 1, or a one-rank group with DVD_FORCE_EXCHANGE=1
         self.stream = None
-        if self.world > 1 and torch.cuda.is_available():
+        if self.active and torch.cuda.is_available():
             # The exchange is ISSUED from a stream of the most urgent priority level; that only orders the event fences around
             # the collective.  The all-reduce kernels themselves run on ProcessGroupNCCL's internal stream, which
             # init_from_env creates high-priority (pg_options, is_high_priority_stream) so that they are dispatched at the next
@@ -118,13 +133,13 @@ class GradExchange:
 
     def start(self, key, flat_grad):
         """Begin averaging `flat_grad` (in place).  Call finish(key) before the buffer is read."""
-        if self.world > 1:
+        if self.active:
             self._launch(key, flat_grad)
 
     def start_range(self, key, flat_grad, lo, hi):
         """Begin averaging flat_grad[lo:hi] (a bucket); several ranges may be pending under one key.  Every rank must
         issue the same ranges in the same order."""
-        if self.world > 1 and hi > lo:
+        if self.active and hi > lo:
             self._launch(key, flat_grad[lo:hi])
 
     def finish(self, key):
@@ -137,7 +152,7 @@ def broadcast_state(nets, flats=()):
     a view of one of them (SN u / v are requires_grad=False parameters) and all buffers (batch-norm statistics).
     Without this, ranks seeded differently (needed for distinct z per rank) would average gradients of DIFFERENT
     models and never agree -- the reference's nn.DataParallel replicates from GPU 0 every forward instead."""
-    if world_size() == 1:
+    if not exchange_on():
         return
     with torch.no_grad():
         for f in flats:
@@ -159,7 +174,7 @@ def shared_seed():
     """One random 63-bit seed agreed by all ranks (drawn on rank 0): seeds the frame-id generator, so every rank samples
     the same k frame ids per step while z / labels stay per rank."""
     seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
-    if world_size() > 1:
+    if exchange_on():
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         s = seed.to(dev)
         dist.broadcast(s, 0)

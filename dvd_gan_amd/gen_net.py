@@ -190,7 +190,7 @@ class Generator(nn.Module):
         b_idx = torch.arange(B, device=dev).view(1, B)
         samp = ((b_idx * T + t_idx) % B).reshape(-1).to(torch.int32)
         cond = zc
-        if self.dp_global and D.world_size() > 1:
+        if self.dp_global and D.exchange_on():
             # one process on the global batch would condition frame (b, t) on row (b*T + t) mod B_global: gather the
             # condition rows of all ranks (rank-major = global batch order) and index them with the GLOBAL b
             cond = D.AllGatherRows.apply(zc)

@@ -63,7 +63,7 @@ class _PlateauLR:
     def step(self, metric):
         if metric is None:
             raise TypeError("step() missing 1 required positional argument: 'metrics'")
-        if D.world_size() > 1:
+        if D.exchange_on():
             # data parallel: every rank must take the SAME lr decision or the replicas' parameters drift apart for good
             # (only gradients are exchanged) -- the schedulers see the mean of the ranks' losses.  (A Python float is accepted
             # like in the single-process path; every rank must call step() every iteration: it is a collective.)
@@ -119,20 +119,20 @@ class Trainer(object):
         prio = os.environ.get("DVD_CHAIN_PRIO", "auto")
         self._chain = None
         self._aux = None          # stream of the discriminator passes over the real clips (see _train_step)
-        if torch.cuda.is_available() and (prio == "1" or (prio == "auto" and self.exchange.world == 1)):
+        if torch.cuda.is_available() and (prio == "1" or (prio == "auto" and not self.exchange.active)):
             self._chain = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
             # opt-in: -1.6 ms of 537 at 64 x 64, but the step DOUBLES at 48 x 128 x 128 (2002 -> 4043 ms; 175 GB of activations: blocks
             # freed on the second stream are not reusable by the first and the allocator falls back to synchronising frees)
-            if self.exchange.world == 1 and os.environ.get("DVD_D_REAL_EARLY", "0") == "1":
+            if not self.exchange.active and os.environ.get("DVD_D_REAL_EARLY", "0") == "1":
                 self._aux = torch.cuda.Stream()
-        self.rank = torch.distributed.get_rank() if self.exchange.world > 1 else 0
+        self.rank = torch.distributed.get_rank() if self.exchange.active else 0
         self.build_model()
         if self.pretrained_model:
             self.load_pretrained_model()
         # data parallel: every rank continues from rank 0's model (parameters, SN u / v, BN statistics); frame ids come
         # from a generator all ranks seed alike, z / labels from each rank's own default generator
         self._sync_replicas()
-        self.frame_gen = torch.Generator().manual_seed(D.shared_seed()) if self.exchange.world > 1 else None
+        self.frame_gen = torch.Generator().manual_seed(D.shared_seed()) if self.exchange.active else None
         # ... and z / z_class of rank r from a generator of its own: distinct noise per replica even when every rank was
         # seeded alike (equal seeds on all ranks would train every replica on the same draws).  Its seed mixes the rank with
         # config.seed when the configuration has one, else with a value DRAWN from the caller's default generator -- so
@@ -140,7 +140,7 @@ class Trainer(object):
         # noise, and a resumed run (which re-seeds or not as the caller likes) does not replay a fixed stream.
         # A single process keeps the default generator -- the reference's behaviour (trainer.py:84-88, 236-240).
         self.noise_gen = None
-        if self.exchange.world > 1:
+        if self.exchange.active:
             base = getattr(c, "seed", None)
             if base is None:
                 base = int(torch.randint(0, 2 ** 31 - 1, (1,)))
@@ -154,7 +154,7 @@ class Trainer(object):
                            self_attn=getattr(c, "g_self_attn", False), sep_attn=getattr(c, "g_sep_attn", False)).to(self.device)
         self.D_s = SpatialDiscriminator(self.ds_chn, self.n_class, compute_dtype=dt).to(self.device)
         self.D_t = TemporalDiscriminator(self.dt_chn, self.n_class, compute_dtype=dt).to(self.device)
-        if self.exchange.world > 1 and self.dp_mode == "global":
+        if self.exchange.active and self.dp_mode == "global":
             from .sn_layers import ConditionalNorm
             self.G.dp_global = True
             for m in self.G.modules():
@@ -172,7 +172,7 @@ class Trainer(object):
         self.g_optimizer = FlatAdam(self.G.parameters(), self.g_lr, betas)
         # (the optional attention blocks sit at the END of the parameter order but finish their gradients late in the
         #  backward pass: with them the generator's gradient goes in one piece)
-        self.G.dp_hooks = self.exchange.world > 1 and not (hasattr(self.G, "self_attn") or hasattr(self.G, "sep_attn"))
+        self.G.dp_hooks = self.exchange.active and not (hasattr(self.G, "self_attn") or hasattr(self.G, "sep_attn"))
         # offset of the first trainable parameter of generator module conv.k in the flat buffers (gradient buckets)
         self._g_bounds, off = {}, 0
         for name, prm in self.G.named_parameters():
@@ -326,7 +326,7 @@ class Trainer(object):
         g_t_loss = self.calc_loss(self.D_t(fake_d, z_class), True)
         self._freeze_d(False)
         self.g_optimizer.zero_grad()
-        if ex.world > 1:
+        if ex.active:
             # bucketed exchange: the tail of the flat gradient buffer (last modules) is final first
             self._g_hi = self.g_optimizer.grad.numel()
 
@@ -338,7 +338,7 @@ class Trainer(object):
             self.G.grad_ready_hook = on_ready
         (g_s_loss + g_t_loss).backward()
         Fn.join_side()
-        if ex.world > 1:
+        if ex.active:
             self.G.grad_ready_hook = None
             ex.start_range("G", self.g_optimizer.grad, 0, self._g_hi)
         ex.finish("G")

@@ -6,7 +6,9 @@
  * from nn.Module.forward.  Each entry point below therefore names the reference call site(s)
  * whose vendor kernel it replaces (file:line under /root/reference).  Conventions:
  *   - plain C: device pointers + sizes, no torch types; every call is asynchronous on `stream`
- *     (a hipStream_t passed as void*), never synchronises the device, keeps no global state;
+ *     (a hipStream_t passed as void*), never synchronises the device.  Process-wide state is limited to three
+ *     caches / debug aids that never change a result: the split-K plan cache of the ConvGRU wavefront (keyed by the
+ *     launch geometry, mutex-protected), the optional profiling hooks (dvd_prof_*) and the dvd_debug_* counters;
  *   - return value: 0 = ok, <0 = DVD_E_* (bad argument / unsupported shape / launch failure);
  *   - activations are channels-last: [frames][T][H][W][C] with C padded to a multiple of 8,
  *     row stride `ld*` in ELEMENTS; spatial extents H, W: powers of two take the fast kernels (LDS-staged footprints,
@@ -21,6 +23,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the declarations of this header are exported */
+#pragma GCC visibility push(default)
 
 #define DVD_F32 0
 #define DVD_BF16 1
@@ -262,6 +266,10 @@ int dvd_convgru_stack_ok(const dvd_gru_stack_desc* d, int backward);
 long long dvd_convgru_stack_ws_floats(const dvd_gru_stack_desc* d);
 int dvd_convgru_stack_forward(const dvd_gru_stack_desc* d, void* stream);
 int dvd_convgru_stack_backward(const dvd_gru_stack_desc* d, void* stream);
+/* Test hook (tests/test_gpu_gru_stack.py): out[0] = floats the last dvd_convgru_stack_ws_floats call asked for (0 when no
+ * member of any grouped launch is split), out[1] = the largest slab cursor any LAUNCHED group has used since the last reset;
+ * reset != 0 clears out[1] afterwards.  After one forward + backward of a stack the two must be equal. */
+void dvd_debug_stack_ws(long long* out, int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Batch norm statistics + conditional batch norm (Module/Normalization.py:78-88; F.batch_norm +
@@ -424,6 +432,7 @@ int dvd_sepattn_backward(int dtype, const void* dy, int ldx, int C, int Cq, cons
 int dvd_clip_to_tensor(const unsigned char* src, const unsigned char* flip, float* dst, long long B, int T, int H, int W,
                        float norm_value, const float* mean_std, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

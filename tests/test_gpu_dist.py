@@ -5,7 +5,10 @@
     match a single-process step on the global batch;
   * dp_mode="global" (cross-replica conditional batch norm + gathered condition rows): the two ranks reproduce ONE
     process on the global batch -- six losses and every gradient of G, D_s and D_t;
-  * the same over RCCL (backend nccl, one rank per GPU) whenever at least two GPUs are visible.
+  * the same over RCCL (backend nccl, one rank per GPU) whenever at least two GPUs are visible;
+  * a ONE-rank RCCL group with the exchange forced on (DVD_FORCE_EXCHANGE=1, dist.forced): the nccl branch of dist.py --
+    ReduceOp.AVG, the high-priority process-group options, all_gather_into_tensor, the bucket hooks and the stream fences,
+    everything except the transport -- must leave a bf16 step at the benchmark's widths BIT-EQUAL to the plain step.
 """
 import os
 import socket
@@ -151,3 +154,67 @@ def test_two_gpus_over_rccl(tmp_path, mode):
         _check_replica_mode(two, one)
     else:
         _check_global_mode(two, one)
+
+
+FORCED_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import importlib.util
+from dvd_gan_amd import dist as D
+mode, forced = sys.argv[3], sys.argv[4] == "1"
+if forced:
+    rank, world, dev = D.init_from_env("nccl")
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and world == 1
+spec = importlib.util.spec_from_file_location("repro_probe", os.path.join(sys.argv[1], "tools", "repro_probe.py"))
+probe = importlib.util.module_from_spec(spec); spec.loader.exec_module(probe)
+from dvd_gan_amd import train_step
+if mode == "global":                      # (tools/repro_probe.build constructs Trainer(...) with the default dp_mode)
+    orig = train_step.Trainer.__init__
+    def init(self, *a, **kw):
+        kw["dp_mode"] = "global"
+        orig(self, *a, **kw)
+    train_step.Trainer.__init__ = init
+    probe.Trainer = train_step.Trainer
+calls = {"n": 0}
+if forced:
+    real_ar = torch.distributed.all_reduce
+    def counting(*a, **kw):
+        calls["n"] += 1
+        return real_ar(*a, **kw)
+    torch.distributed.all_reduce = counting
+losses, state = probe.run(32, 8, 2, 7, 2)
+torch.cuda.synchronize()
+torch.save({"losses": losses, "state": {k: v.cpu() for k, v in state.items()}, "all_reduces": calls["n"]}, sys.argv[2])
+if forced:
+    torch.distributed.barrier(); torch.distributed.destroy_process_group()
+'''
+
+
+def _forced_run(tmp, mode, forced):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = os.path.join(tmp, "forced_worker.py")
+    open(script, "w").write(FORCED_WORKER)
+    out = os.path.join(tmp, f"forced.{mode}.{int(forced)}")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", DVD_FORCE_EXCHANGE="1" if forced else "0")
+    env.pop("DVD_DIST_BACKEND", None)
+    assert subprocess.call([sys.executable, script, ROOT, out, mode, "1" if forced else "0"], env=env, timeout=900) == 0
+    return torch.load(out)
+
+
+@pytest.mark.parametrize("mode", ["replica", "global"])
+def test_one_rank_rccl_group_with_forced_exchange_equals_plain_step_bitwise(tmp_path, mode):
+    """trainer.py:353-359's replacement over the nccl backend, on ONE GPU: two bf16 steps at ch=32 (the reproducibility test's
+    shape) with every gradient all-reduced by RCCL (AVG over one rank), the generator's gradient in its four buckets behind the
+    stage hooks, and in "global" mode the batch-norm sums / condition rows through all_reduce / all_gather_into_tensor.  Losses,
+    every gradient the optimizers saw and every parameter / buffer afterwards equal the plain single-process step bit for bit."""
+    plain = _forced_run(str(tmp_path), "replica", False)
+    forced = _forced_run(str(tmp_path), mode, True)
+    # per step: D_s + D_t + four generator buckets (+ the cross-replica statistics in global mode)
+    assert forced["all_reduces"] >= 2 * 6, forced["all_reduces"]
+    if mode == "global":
+        assert forced["all_reduces"] > 2 * 6 + 16
+    assert plain["losses"] == forced["losses"], (plain["losses"], forced["losses"])
+    assert len(plain["state"]) > 600 and plain["state"].keys() == forced["state"].keys()
+    bad = [k for k in plain["state"] if not torch.equal(plain["state"][k], forced["state"][k])]
+    assert not bad, bad[:10]

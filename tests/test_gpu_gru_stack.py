@@ -128,3 +128,90 @@ def test_wavefront_inference_form(monkeypatch):
         b = gru.run(xc, T, shared)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+# ------------------------------------------------------------------ the schedule the benchmark ships (B = 64, real widths)
+# Generator.py:43-55 at ch = 32: three ConvGRUs of 256 / 512 / 256 channels (3, 5, 3 taps) on 4, 8 and 16 pixel frames, one of
+# 128 / 256 / 128 (3, 5, 5 taps) on 32 pixel frames; the first one reads one shared input for every step (Generator.py:87-97).
+# plan_splits picks the per-member split-K factors from the tile counts, i.e. from B: these are the plans bench.py executes.
+PROD = [   # T, B, S, cin, hidden sizes, kernel sizes, shared input, supplied initial states, split-K cap (0 = production policy)
+    (6, 64, 4, 256, [256, 512, 256], [3, 5, 3], True, None, 0),
+    (48, 64, 4, 256, [256, 512, 256], [3, 5, 3], True, None, 0),
+    (6, 64, 8, 256, [256, 512, 256], [3, 5, 3], False, None, 0),
+    (48, 64, 8, 256, [256, 512, 256], [3, 5, 3], False, None, 0),
+    (6, 64, 16, 256, [256, 512, 256], [3, 5, 3], False, None, 0),
+    (6, 64, 32, 128, [128, 256, 128], [3, 5, 5], False, None, 0),
+    (6, 64, 8, 256, [256, 512, 256], [3, 5, 3], False, (True, True, True), 0),      # configs[4]: states carried in
+]
+
+
+def _stack_ws():
+    import ctypes as C
+    from dvd_gan_amd import lib as L
+    out = (C.c_longlong * 2)()
+    L.lib().dvd_debug_stack_ws(out, 1)
+    return int(out[0]), int(out[1])
+
+
+@pytest.mark.parametrize("case", PROD, ids=lambda c: f"T{c[0]}B{c[1]}S{c[2]}h{c[4][0]}{'s' if c[6] else ''}{'i' if c[7] else ''}")
+def test_production_schedule_at_benchmark_size(case, monkeypatch):
+    """The four generator ConvGRUs at their real widths and B = 64 under the production split-K policy against the layer-by-layer
+    path (same bounds as the WIDE cases).  Also: every split-K ticket is back at zero, and the slab workspace the sizing query
+    asked for is EXACTLY the largest slab cursor a launched group used (an over- or under-sized workspace means the dry run
+    and the launch walked different schedules -- the round-5 slab overrun faulted only in the full step)."""
+    from dvd_gan_amd import functional as Fn
+    from dvd_gan_amd import lib as L
+    gru, x, gys, h0s = _build(case)
+    monkeypatch.setattr(Fn, "GRU_STACK", True)
+    L.reset_gru_tickets()
+    _stack_ws()
+    new = _run(gru, case, x, gys, h0s, all_layers=False)
+    sized, used = _stack_ws()
+    assert int(L.gru_tickets(torch.device(DEV, torch.cuda.current_device())).abs().sum()) == 0
+    assert sized > 0, "the production plan of a benchmark-sized stack splits no member at all?"
+    assert used == sized, (used, sized)
+    monkeypatch.setattr(Fn, "GRU_STACK", False)
+    old = _run(gru, case, x, gys, h0s, all_layers=False)
+    for l, (a, b) in enumerate(zip(new["ys"], old["ys"])):
+        assert torch.isfinite(a).all()
+        assert _rel(a, b) < 4e-3, (l, _rel(a, b))
+    assert _rel(new["dx"], old["dx"]) < 1e-2
+    for a, b in zip(new["dh0"], old["dh0"]):
+        assert _rel(a, b) < 1e-2
+    for (k, _), a, b in zip(gru.named_parameters(), new["dw"], old["dw"]):
+        assert _rel(a, b) < 1e-2, (k, _rel(a, b))
+
+
+@pytest.mark.parametrize("S,shared", [(4, True), (8, False)], ids=["gru0", "gru1"])
+def test_benchmark_sized_stack_against_the_oracle(S, shared, monkeypatch):
+    """gru0 (4 x 4 frames, shared input) and gru1 (8 x 8) of the generator at ch = 32 and B = 64, T = 4: forward and BPTT of the
+    wavefront under the production plans against the CPU restatement of ConvGRU.py:29-54, 104-133 (oracle.convgru), at the
+    bf16 module bounds of tests/test_gpu_fullwidth.py (outputs 2e-2, input gradient 5e-2, parameter gradients cosine 0.999 / 5e-2)."""
+    from oracle import dvdgan_cpu as O
+    from dvd_gan_amd import functional as Fn
+    T, B, cin, hids, ks = 4, 64, 256, [256, 512, 256], [3, 5, 3]
+    case = (T, B, S, cin, hids, ks, shared, None, 0)
+    gru, x, gys, _ = _build(case)
+    monkeypatch.setattr(Fn, "GRU_STACK", True)
+    got = _run(gru, case, x, gys, None, all_layers=False)
+    # ---- the oracle on the same weights / inputs (fp32, CPU)
+    torch.set_num_threads(min(16, __import__("os").cpu_count() or 1))
+    sd = {k: v.detach().float().cpu() for k, v in gru.state_dict().items()}
+    for p in sd.values():
+        p.requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    hidden, ys = None, []
+    for t in range(T):
+        hidden = O.convgru(sd, "", xr if shared else xr[t * B:(t + 1) * B], hidden, 3)
+        ys.append(hidden[-1])
+    y = torch.cat(ys, 0)
+    (y * gys[-1]).sum().backward()
+    assert _rel(got["ys"][-1].cpu(), y.detach()) < 2e-2
+    assert _rel(got["dx"].cpu(), xr.grad) < 5e-2
+    scale = max(float(p.grad.abs().max()) for p in sd.values())
+    for (k, _), g in zip(gru.named_parameters(), got["dw"]):
+        ref = sd[k].grad
+        if float(ref.abs().max()) < 1e-4 * scale:
+            continue
+        cos = float((g.cpu().double() * ref.double()).sum() / (g.cpu().double().norm() * ref.double().norm()))
+        assert cos > 0.999 and _rel(g.cpu(), ref) < 5e-2, (k, cos, _rel(g.cpu(), ref))
