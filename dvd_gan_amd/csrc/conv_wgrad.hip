@@ -611,6 +611,290 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
         }
 }
 
+// ============================================================================ backward-weight, one filter row, ONE WAVE PER SIMD (round 6)
+// The 8-wave row kernel above is held by its LDS traffic on 3-tap filters (pipe busy 0.47-0.52 with clock headroom,
+// profiles/r05_pmc_wgrad.json): 229 staged bytes and 1.67 transposing reads per MFMA.  More MFMAs per staged byte need a larger
+// channel tile, and the accumulators of a larger tile do not fit the 256 registers a wave has at two waves per SIMD.  This form
+// runs FOUR waves per workgroup, one per SIMD, each with the whole 512-entry register file (accumulators spill over into AGPRs):
+//   workgroup tile  (WCO * AW * 32) out-channels x (WCI * BW * 32) in-channels x KW taps, waves arranged WCO x WCI
+//   wave tile       AW x BW x KW accumulators of 32 x 32  (3 taps, 256 x 128: 4 x 2 x 3 = 24 = 384 registers)
+//   per 32-pixel sub-step and wave: 2 * KW * BW units of AW MFMAs; A fragments of a k half stay in registers for all its units,
+//   B fragments are read two units ahead -> (AW + KW * BW) transposing reads per k half: 0.83 per MFMA, 146 staged bytes per MFMA.
+// With one wave per SIMD nothing covers a wave that waits, so the loop is ONE software pipeline across sub-steps:
+//   * staging registers are in flight all the time: chunk i of sub-step s+1 is written to the LDS ring during sub-step s and its
+//     register is re-loaded at once with chunk i of sub-step s+2 (a load has a whole sub-step, ~1500 cycles, to land);
+//   * the ring has three sub-step buffers; the barrier of sub-step s sits UB units into it (all stores of s+1 done), the units
+//     behind it already read the first fragments of sub-step s+1, so the matrix pipe is fed across the barrier;
+//   * every LDS / VMEM operation is pinned between two MFMA units (sched_barrier), ~1 staging operation per unit.
+// Same LDS images, loaders, slice workspace, bias shares and reduce kernels as conv_wgrad_row_kernel (no x2-upsampled input).
+template <int KW, int AW, int BW, int WCO, int WCI, bool RELU>
+__global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
+    static_assert(WCO * WCI == 4, "four waves, one per SIMD");
+    constexpr int NTt = 256, BMc = WCO * AW * 32, NHB = WCI * BW, BNc = NHB * 32;
+    constexpr int RSA = BMc * 2 + 64;
+    constexpr int TA_BYTES = 32 * RSA;
+    constexpr int XROWS = KW == 5 ? 64 : 48, XHALF = XROWS * 64, TB_BYTES = NHB * XHALF;
+    constexpr int SUB = TA_BYTES + TB_BYTES;
+    constexpr int EPIB = 4 * 32 * 32 * 4, REDB = NTt * 8 * 4;
+    constexpr int LDSB = 3 * SUB > EPIB ? (3 * SUB > REDB ? 3 * SUB : REDB) : (EPIB > REDB ? EPIB : REDB);
+    __shared__ __attribute__((aligned(16))) char smem[LDSB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WCI, wn = wave % WCI;
+    int bx = blockIdx.x, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, total = gx * gridDim.z, lin = bx + gx * bz;
+        const int xcd = lin & 7, qd = total >> 3, rr = total & 7;
+        const int lp = (xcd < rr ? xcd * (qd + 1) : rr * (qd + 1) + (xcd - rr) * qd) + (lin >> 3);
+        bz = lp / gx; bx = lp - bz * gx;
+    }
+    const int tiles = p.tiles_co * p.tiles_ci;
+    const int irow = bx / tiles;
+    const int rem = bx - irow * tiles;
+    const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
+    const int co0 = tco * BMc, ci0 = tci * BNc;
+    constexpr int pad = KW >> 1;
+    const int it = irow / KW, iy = irow - it * KW;
+    const int dyl = iy - pad, dtl = it - (p.kt >> 1);
+    const int m_begin = bz * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    f32x16 acc[AW][BW][KW];
+    {
+        const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < AW; ++a)
+#pragma unroll
+            for (int b = 0; b < BW; ++b)
+#pragma unroll
+                for (int t = 0; t < KW; ++t) acc[a][b][t] = zacc;
+    }
+    const int xbase_row = max(0, m_begin - p.maxshift);
+    const size_t xbase_b = (size_t)xbase_row * p.ldx * 2, ybase_b = (size_t)m_begin * p.ldy * 2;
+    const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + xbase_b), 0, xleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)xleft, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ybase_b), 0, yleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)yleft, 0x00020000);
+    const int segw = min(p.W, 32), logsegw = min(p.logW, 5);
+    const int fpr = segw + KW - 1, frows = (32 >> logsegw) * fpr;
+    // staging chunks of one sub-step: NPA of dy, NXL of the x footprint (16 bytes each per thread)
+    constexpr int CPRA = BMc / 8, RPPA = NTt / CPRA, NPA = 32 / RPPA;
+    const int rra = tid / CPRA, cka = tid % CPRA;
+    const int cy = co0 + cka * 8;
+    const bool cyv = cy < p.Cy;
+    constexpr int CPX = NHB * 4;
+    constexpr int NXL = (XROWS * CPX + NTt - 1) / NTt;
+    constexpr int NOPS = NPA + NXL;
+    int xseg[NXL], xj[NXL], xdst[NXL];
+    unsigned xcb[NXL];
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+        const int q = tid + i * NTt, row = q / CPX, c8 = q % CPX;
+        xseg[i] = row / fpr;
+        xj[i] = row - xseg[i] * fpr;
+        const int cx = ci0 + c8 * 8;
+        xcb[i] = (row < frows && cx < p.C) ? (unsigned)cx * 2 : 0xffffffffu;            // 0xffffffff: never a valid chunk
+        xdst[i] = q < XROWS * CPX ? (c8 >> 2) * XHALF + row * 64 + (c8 & 3) * 16 : -1;
+    }
+    u32x4 R[NOPS];
+    struct Geo { int x0, y, frow0; bool tok; };
+    auto geo = [&](int mk) __attribute__((always_inline)) -> Geo {
+        Geo g;
+        g.x0 = mk & (p.W - 1); g.y = (mk >> p.logW) & (p.H - 1);
+        g.frow0 = mk - (g.y << p.logW) - g.x0;
+        g.tok = mk < m_end;
+        if (p.kt > 1) {
+            const int tt = (mk >> (p.logW + p.logH)) % p.T + dtl;
+            g.tok = g.tok && (unsigned)tt < (unsigned)p.T;
+            g.frow0 += dtl << (p.logW + p.logH);
+        }
+        return g;
+    };
+    auto load_op = [&](int op, int mk, const Geo& g) __attribute__((always_inline)) {
+        if (op < NPA) {
+            const int m = mk + rra + op * RPPA;
+            const unsigned off = (cyv && m < m_end) ? (unsigned)(m - m_begin) * ((unsigned)p.ldy * 2) + cy * 2 : 0xffffffffu;
+            R[op] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+        } else {
+            const int i = op - NPA;
+            const int lf = g.y + xseg[i], fo = lf >> p.logH;
+            const int yy = (lf & (p.H - 1)) + dyl;
+            const int xx = g.x0 + xj[i] - pad;
+            const bool ok = xcb[i] != 0xffffffffu && g.tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const int row = g.frow0 + (fo << (p.logW + p.logH)) + (yy << p.logW) + xx;
+            const unsigned off = ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i] : 0xffffffffu;
+            R[op] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+        }
+    };
+    // bias gradient shares: as in conv_wgrad_row_kernel (sub-step n belongs to share n % nshare)
+    const bool spread = p.ws != nullptr;
+    const bool do_bias = p.dbias != nullptr && dtl == 0 && (spread || (dyl == 0 && tci == 0));
+    const int nshare = spread ? KW * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
+    int bphase = 0;
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto store_op = [&](int op, char* st, bool mine) __attribute__((always_inline)) {
+        if (op < NPA) {
+            *reinterpret_cast<u32x4*>(st + (rra + op * RPPA) * RSA + cka * 16) = R[op];
+            if (mine) {
+                bs[0] += __uint_as_float(R[op].x << 16); bs[1] += __uint_as_float(R[op].x & 0xffff0000u);
+                bs[2] += __uint_as_float(R[op].y << 16); bs[3] += __uint_as_float(R[op].y & 0xffff0000u);
+                bs[4] += __uint_as_float(R[op].z << 16); bs[5] += __uint_as_float(R[op].z & 0xffff0000u);
+                bs[6] += __uint_as_float(R[op].w << 16); bs[7] += __uint_as_float(R[op].w & 0xffff0000u);
+            }
+        } else {
+            const int i = op - NPA;
+            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(st + TA_BYTES + xdst[i]) = RELU ? relu16_bf16(R[op]) : R[op];
+        }
+    };
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int frow = (g16 >> 1) * 8 + (i16 >> 2), fcol2 = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;
+    auto tr2 = [&](const char* lo_, const char* hi_) __attribute__((always_inline)) -> bf16x8 {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_);
+        s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, f);
+    };
+    int xoffs[2][2];                                             // [k half][lo / hi 4-row block] of this wave's first 32-channel block
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            const int pk = kb * 16 + frow + hl * 4;
+            const int fr = (pk >> logsegw) * fpr + (pk & (segw - 1));
+            xoffs[kb][hl] = TA_BYTES + wn * BW * XHALF + fr * 64 + fcol2;
+        }
+    const int aoff = frow * RSA + fcol2 + (wm * AW * 32) * 2;
+    constexpr int UPK = KW * BW, NU = 2 * UPK;                   // units per k half / per sub-step; unit = (k half, tap, in-channel block)
+    constexpr int UB = NU >= 8 ? NU - 3 : NU - 2;                // the sub-step's barrier sits in front of unit UB
+    static_assert(UB >= UPK, "the next sub-step's A fragments reuse the first k half's registers");
+    bf16x8 fa[2][AW], fb[3];
+    auto ldA = [&](const char* st, int kb, int a) __attribute__((always_inline)) {
+        const char* pz = st + aoff + kb * 16 * RSA + a * 64;
+        fa[kb][a] = tr2(pz, pz + 4 * RSA);
+    };
+    auto ldB = [&](const char* st, int u, int slot) __attribute__((always_inline)) {
+        const int kb = u / UPK, t = (u % UPK) / BW, b = u % BW;
+        fb[slot] = tr2(st + xoffs[kb][0] + t * 64 + b * XHALF, st + xoffs[kb][1] + t * 64 + b * XHALF);
+    };
+    if (m_begin < m_end) {
+        // prologue: sub-step 0 into ring slot 0, sub-step 1 into the registers
+        {
+            const Geo g0 = geo(m_begin);
+#pragma unroll
+            for (int op = 0; op < NOPS; ++op) load_op(op, m_begin, g0);
+            const bool mine = do_bias && bphase == myshare;
+            if (++bphase == nshare) bphase = 0;
+#pragma unroll
+            for (int op = 0; op < NOPS; ++op) store_op(op, &smem[0], mine);
+            const Geo g1 = geo(m_begin + 32);
+#pragma unroll
+            for (int op = 0; op < NOPS; ++op) load_op(op, m_begin + 32, g1);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int a = 0; a < AW; ++a) ldA(&smem[0], 0, a);
+            ldB(&smem[0], 0, 0);
+            ldB(&smem[0], 1, 1);
+        }
+        char* rd = &smem[0];
+        char* nx = &smem[SUB];
+        char* fr_ = &smem[2 * SUB];
+        for (int mk = m_begin; mk < m_end; mk += 32) {
+            const Geo gl = geo(mk + 64);
+            const bool mine = do_bias && bphase == myshare;              // share of the sub-step being stored (mk + 32)
+            if (++bphase == nshare) bphase = 0;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                // staging: chunk ops spread over the units in front of the barrier
+#pragma unroll
+                for (int op = 0; op < NOPS; ++op)
+                    if ((op * UB) / NOPS == u) {
+                        store_op(op, nx, mine);
+                        load_op(op, mk + 64, gl);
+                    }
+                if (u == UB) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's stores of sub-step s+1 are in the LDS
+                    __builtin_amdgcn_s_barrier();
+                }
+                // B fragment two units ahead (the last two units reach into the next sub-step)
+                if (u + 2 < NU) ldB(rd, u + 2, (u + 2) % 3);
+                else ldB(nx, u + 2 - NU, (u + 2) % 3);
+                // A fragments: second k half during the first, the next sub-step's first k half behind the barrier
+                if (u < UPK) {
+#pragma unroll
+                    for (int a = 0; a < AW; ++a)
+                        if ((a * UPK) / AW == u) ldA(rd, 1, a);
+                } else if (u >= UB) {
+#pragma unroll
+                    for (int a = 0; a < AW; ++a)
+                        if ((a * (NU - UB)) / AW == u - UB) ldA(nx, 0, a);
+                }
+                {
+                    const int kb = u / UPK, t = (u % UPK) / BW, b = u % BW;
+#pragma unroll
+                    for (int a = 0; a < AW; ++a)
+                        acc[a][b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][a], fb[u % 3], acc[a][b][t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            char* t_ = rd; rd = nx; nx = fr_; fr_ = t_;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): two sub-steps of prefetch are still in flight
+        __syncthreads();
+    }
+    if (do_bias) {
+        float* red = reinterpret_cast<float*>(&smem[0]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
+        __syncthreads();
+        if (tid < CPRA) {
+            for (int k = 0; k < 8; ++k) {
+                float a = 0.f;
+                for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
+                const int co = co0 + tid * 8 + k;
+                if (spread) p.wsb[((size_t)bz * gridDim.x + bx) * BMc + tid * 8 + k] = a;
+                else if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
+            }
+        }
+        __syncthreads();
+    }
+    float* ep = reinterpret_cast<float*>(&smem[0]) + wave * (32 * 32);
+#pragma unroll
+    for (int a = 0; a < AW; ++a)
+#pragma unroll
+        for (int b = 0; b < BW; ++b)
+#pragma unroll
+            for (int t = 0; t < KW; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[a][b][t][r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int ci = ci0 + (wn * BW + b) * 32 + (lane & 31);
+                const int cob = co0 + (wm * AW + a) * 32 + (lane >> 5);
+                const int tap = irow * KW + t;
+                if (p.ws) {
+                    float* wt = p.ws + (((size_t)bz * gridDim.x + bx) * KW + t) * (size_t)(BMc * BNc) +
+                                (size_t)((wm * AW + a) * 32) * BNc + (wn * BW + b) * 32;
+#pragma unroll 1
+                    for (int j = 0; j < 16; ++j)
+                        wt[(size_t)(2 * j + (lane >> 5)) * BNc + (lane & 31)] = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+                } else if (ci < p.Cin_real) {
+                    float* dst = p.dw + ci * p.s_ci + tap * p.s_tap;
+#pragma unroll 1
+                    for (int j = 0; j < 16; ++j) {
+                        const int co = cob + 2 * j;
+                        const float v = ep[(2 * j + (lane >> 5)) * 32 + (lane & 31)];
+                        if (co < p.Cout && v != 0.f) atomicAdd(dst + co * p.s_co, v);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+}
+
 // reduction of the row kernel's partial tiles: dw[co][ci][iy*KW + t] += sum over slices
 struct WgRowRedK { const float* ws; float* dw; int nslice, gx, tiles_co, tiles_ci, BMc, BNc, KW, Cout, Cin_real; long long s_co, s_ci, s_tap; int overwrite; };
 // sum over the slices of four consecutive partial-tile elements (16-byte loads, four slices requested before the first addition;
@@ -763,7 +1047,13 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         // 128-channel output tile, 5 taps: take 128 input channels too (one 8-wave workgroup per CU whose halves stagger their
         // loads, like the 256-channel tile) when that pads Cin no further: 1.20 -> 1.33 PF/s on 3.1 M x 256 -> 384; with 3 taps
         // the two 4-wave workgroups per CU of the 64-channel form stay 3 % ahead
-        if (ta == 2 && d->kw == 5 && !d->up2 && (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64) tb = 2;
+        const bool ci128 = (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64;      // 128-channel input tiles pad no further
+        if (ta == 2 && d->kw == 5 && !d->up2 && ci128) tb = 2;
+#ifndef DVD_WG_ROW4
+#define DVD_WG_ROW4 1
+#endif
+        // 3 taps (round 6): one wave per SIMD with the whole register file -- 256 x 128 (or 128 x 128) channel tiles, mode 2
+        if (DVD_WG_ROW4 && d->kw == 3 && !d->up2 && ci128 && ta >= 2) { mode = 2; tb = 2; if (DVD_WG_ROW4 == 1) ta = 2; }
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
@@ -786,8 +1076,8 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         //  chain's kernels no longer leave the side stream the CUs they used to -- fewer, longer slices win on the STEP: 256 503.4 / 503.8,
         //  384 498.1 / 498.1, 512 495.6 / 495.7, 768 497.7 / 498.5, 1024 498.4 / 497.3, 1536 500.4 / 500.3, 3072 501.3 ms, one box)
         constexpr long long tgt_row = 512;
-        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps);
-        msplit = ((mode == 1 ? tgt_row : tgt) + base - 1) / base;
+        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode >= 1 ? d->kt * d->kh : ntaps);
+        msplit = ((mode >= 1 ? tgt_row : tgt) + base - 1) / base;
         long long cap = M / minrows > 0 ? M / minrows : 1;
         if (ntaps == 1 && cap * base < 256) {
             // short 1 x 1 layers (shortcut and attention projections on <= 16-pixel maps): 16 workgroups of 4096 rows each took
@@ -798,7 +1088,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         if (msplit > cap) msplit = cap;
         // whole rounds: the workgroups run `conc` at a time (register / LDS limited); a grid a few workgroups over a
         // multiple of that pays a full extra round (20 x 103 = 2060 workgroups = 8.05 rounds of 256 -> 9 rounds)
-        const long long conc = 256ll * ((mode == 1 && (ta == 4 || tb == 2)) ? 1 : 2);
+        const long long conc = 256ll * ((mode >= 1 && (ta == 4 || tb == 2)) ? 1 : 2);
         if (base * msplit > conc) {
             const long long rounds = (base * msplit + conc / 2) / conc;           // nearest
             long long ms2 = rounds * conc / base;
@@ -815,7 +1105,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     if (rows < 32) rows = 32;
     msplit = (M + rows - 1) / rows;
     p.rows_per_split = (int)rows;
-    grid = dim3(p.tiles_co * p.tiles_ci * (mode == 1 ? d->kt * d->kh : ntaps), 1, (unsigned)msplit);
+    grid = dim3(p.tiles_co * p.tiles_ci * (mode >= 1 ? d->kt * d->kh : ntaps), 1, (unsigned)msplit);
     return DVD_OK;
 }
 
@@ -823,7 +1113,7 @@ extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
     WgK p; dim3 grid; int ta, tb, mode; long long msplit;
     if (const long long thin = dvd_wgrad_thin_ws_floats(d)) return thin;       // 3 (8) channels on one side: wgrad_thin.hip
     if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
-    if (mode == 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) + msplit * (long long)grid.x * (ta * 64);   // + bias partials
+    if (mode >= 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) + msplit * (long long)grid.x * (ta * 64);   // + bias partials
     return msplit * (long long)grid.x * (ta * 64) * (tb * 64) + msplit * (long long)p.tiles_co * (ta * 64);      // + bias partials
 }
 
@@ -845,13 +1135,13 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
         if (!p.ws && hipMemsetAsync(d->dw, 0, (size_t)d->Cout * d->Cin_real * ntaps * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return DVD_E_LAUNCH;                   // single slice: the kernel adds with atomics
     }
-    p.wsb = !p.ws ? nullptr : mode == 1 ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64)
+    p.wsb = !p.ws ? nullptr : mode >= 1 ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64)
                                         : p.ws + msplit * (long long)grid.x * (ta * 64) * (tb * 64);
     ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
-    prof.r.variant = mode == 1 ? 1 : 2;
-    if (mode == 1) {
+    prof.r.variant = mode >= 1 ? 1 : 2;
+    if (mode >= 1) {
 #define LAUNCH_ROW(WM_, KW_)                                                                        \
         do { if (d->relu_in) conv_wgrad_row_kernel<WM_, KW_, true><<<grid, WM_ * 128, 0, st>>>(p);      \
              else conv_wgrad_row_kernel<WM_, KW_, false><<<grid, WM_ * 128, 0, st>>>(p); } while (0)
@@ -861,6 +1151,15 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
 #define LAUNCH_ROW_W(KW_)                                                                           \
         do { if (d->relu_in) conv_wgrad_row_kernel<2, KW_, true, false, 4><<<grid, 512, 0, st>>>(p);    \
              else conv_wgrad_row_kernel<2, KW_, false, false, 4><<<grid, 512, 0, st>>>(p); } while (0)
+        if (mode == 2) {
+#if DVD_WG_ROW4 == 2
+            if (ta == 4) { if (d->relu_in) conv_wgrad_row4_kernel<3, 4, 2, 2, 2, true><<<grid, 256, 0, st>>>(p);
+                           else conv_wgrad_row4_kernel<3, 4, 2, 2, 2, false><<<grid, 256, 0, st>>>(p); }
+            else
+#endif
+                         { if (d->relu_in) conv_wgrad_row4_kernel<3, 4, 1, 1, 4, true><<<grid, 256, 0, st>>>(p);
+                           else conv_wgrad_row4_kernel<3, 4, 1, 1, 4, false><<<grid, 256, 0, st>>>(p); }
+        } else
         if (d->up2) { if (ta == 4) LAUNCH_ROW_UP(4); else if (ta == 2) LAUNCH_ROW_UP(2); else LAUNCH_ROW_UP(1); }
         else if (tb == 2) { if (d->kw == 5) LAUNCH_ROW_W(5); else LAUNCH_ROW_W(3); }
         else

@@ -40,11 +40,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if use_cuda else "gloo")
         kw = {}
-        if backend == "nccl" and os.environ.get("DVD_EXCHANGE_PRIO", "1") != "0":
+        if backend == "nccl" and exchange_priority():
             # RCCL's kernels run on ProcessGroupNCCL's OWN internal stream, whatever stream the collective was issued from
             # (the issuing stream is only fenced with events): that stream is high-priority only when the group is created
-            # with this option.  Without it the all-reduce kernels queue behind the step's launches (two workgroups on every
-            # CU, back to back) at every kernel boundary.
+            # with this option.  OFF by default since round 6 (see exchange_priority).
             opts = nccl_high_priority_options()
             if opts is not None:
                 kw["pg_options"] = opts
@@ -60,6 +59,17 @@ def nccl_high_priority_options():
         return opts
     except (AttributeError, RuntimeError):
         return None
+
+
+def exchange_priority():
+    """DVD_EXCHANGE_PRIO=1: high-priority process-group stream + exchange stream.  Default 0 since round 6 -- the first
+    measurement of the nccl branch (one-rank RCCL group, `bench.py --force-exchange`, B=64, two boxes): with the urgent
+    level the step runs 523.9 / 536.5 ms against 453.4 / 477.8 plain (+15 / +12 %); with every stream of the data-parallel
+    step at the normal level 458.5 / 478.9 ms (+1.1 / +0.2 %).  HIP has two levels here (priority_range (0, -1)): an urgent
+    RCCL stream ranks above the step's own chain, and its event fences stall the chain far longer than the 0.8 ms the
+    547 MB all-reduce kernel itself takes (tools: profiles/r06_forced_exchange.txt).  No multi-GPU hardware was available:
+    with real peers the trade may differ, the switch stays."""
+    return os.environ.get("DVD_EXCHANGE_PRIO", "0") == "1"
 
 
 def world_size():
@@ -111,36 +121,38 @@ class GradExchange:
         self.active = exchange_on()           # world > 1, or a one-rank group with DVD_FORCE_EXCHANGE=1
         self.stream = None
         if self.active and torch.cuda.is_available():
-            # The exchange is ISSUED from a stream of the most urgent priority level; that only orders the event fences around
-            # the collective.  The all-reduce kernels themselves run on ProcessGroupNCCL's internal stream, which
-            # init_from_env creates high-priority (pg_options, is_high_priority_stream) so that they are dispatched at the next
-            # kernel boundary instead of behind the step's queued launches.  DVD_EXCHANGE_PRIO=0 switches both off.
-            # (No multi-GPU hardware was available to this build: the setting is by construction, not by measurement.)
-            hi = torch.cuda.Stream.priority_range()[1] if os.environ.get("DVD_EXCHANGE_PRIO", "1") != "0" else 0
+            # The exchange is ISSUED from its own stream; that only orders the event fences around the collective.  The
+            # all-reduce kernels themselves run on ProcessGroupNCCL's internal stream.  Both are normal-priority streams
+            # unless DVD_EXCHANGE_PRIO=1 (exchange_priority: the urgent level measured 12-15 % slower on a one-rank group).
+            hi = torch.cuda.Stream.priority_range()[1] if exchange_priority() else 0
             self.stream = torch.cuda.Stream(priority=hi)
         self.pending = {}
 
-    def _launch(self, key, view):
+    def _launch(self, key, view, after=()):
         if self.stream is None:                       # CPU / gloo: synchronous
             _avg_(view)
             return
         self.stream.wait_stream(torch.cuda.current_stream())
+        for s in after:                               # producers on other streams (the weight-gradient side stream): the EXCHANGE
+            if s is not None:                         # waits for them, the step's chain does not
+                self.stream.wait_stream(s)
         with torch.cuda.stream(self.stream):
             _avg_(view)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.pending.setdefault(key, []).append(ev)
 
-    def start(self, key, flat_grad):
-        """Begin averaging `flat_grad` (in place).  Call finish(key) before the buffer is read."""
+    def start(self, key, flat_grad, after=()):
+        """Begin averaging `flat_grad` (in place).  Call finish(key) before the buffer is read.  `after`: further streams
+        whose queued work produces the buffer (the exchange stream waits for them; the caller's stream is not fenced)."""
         if self.active:
-            self._launch(key, flat_grad)
+            self._launch(key, flat_grad, after)
 
-    def start_range(self, key, flat_grad, lo, hi):
+    def start_range(self, key, flat_grad, lo, hi, after=()):
         """Begin averaging flat_grad[lo:hi] (a bucket); several ranges may be pending under one key.  Every rank must
         issue the same ranges in the same order."""
         if self.active and hi > lo:
-            self._launch(key, flat_grad[lo:hi])
+            self._launch(key, flat_grad[lo:hi], after)
 
     def finish(self, key):
         for e in self.pending.pop(key, ()):

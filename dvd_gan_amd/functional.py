@@ -54,6 +54,11 @@ def side_stream():
     return _SIDE["stream"]
 
 
+def side_stream_if_any():
+    """The weight-gradient stream if one has been created (None before the first side launch)."""
+    return _SIDE["stream"]
+
+
 def _side_run(fn, *tensors):
     """fn() launches weight-gradient kernels: on the side stream, ordered after the current stream's queue."""
     with _on_side(*tensors):

@@ -172,7 +172,7 @@ class Trainer(object):
         self.g_optimizer = FlatAdam(self.G.parameters(), self.g_lr, betas)
         # (the optional attention blocks sit at the END of the parameter order but finish their gradients late in the
         #  backward pass: with them the generator's gradient goes in one piece)
-        self.G.dp_hooks = self.exchange.active and not (hasattr(self.G, "self_attn") or hasattr(self.G, "sep_attn"))
+        self.G.dp_hooks = self.exchange.active and os.environ.get("DVD_DP_HOOKS", "1") != "0" and not (hasattr(self.G, "self_attn") or hasattr(self.G, "sep_attn"))
         # offset of the first trainable parameter of generator module conv.k in the flat buffers (gradient buckets)
         self._g_bounds, off = {}, 0
         for name, prm in self.G.named_parameters():
@@ -332,8 +332,10 @@ class Trainer(object):
 
             def on_ready(first_done, self=self, ex=ex):
                 lo = self._g_bounds[first_done]
-                Fn.join_side()                    # the bucket's weight gradients were queued on the side stream
-                ex.start_range("G", self.g_optimizer.grad, lo, self._g_hi)
+                # the bucket's weight gradients were queued on the side stream: the EXCHANGE stream waits for them -- the
+                # step's chain is not fenced (round 6: joining the side stream here serialised the backward pass behind every
+                # queued weight-gradient launch three times per step, bench.py --force-exchange)
+                ex.start_range("G", self.g_optimizer.grad, lo, self._g_hi, after=(Fn.side_stream_if_any(),))
                 self._g_hi = min(self._g_hi, lo)
             self.G.grad_ready_hook = on_ready
         (g_s_loss + g_t_loss).backward()

@@ -63,6 +63,11 @@ CASES = [
     (33, 24, 120, (32, 32), (5, 5), False, False),   # 128-channel tile, 64 input channels, several ragged row slices
     (6, 128, 120, (16, 16), (5, 5), False, False),   # 128 x 128-channel tile (8 waves), 5 taps
     (2, 256, 384, (32, 32), (3, 3), False, True),    # 128 x 128-channel tile, 3 x 2 tiles, ReLU on the staged input
+    # one-wave-per-SIMD filter-row kernel (round 6: 3 taps, Cout > 64, input channels in 128-wide tiles): its line geometries
+    (5, 128, 136, (8, 8), (3, 3), False, True),      # W = 8: four lines per step, ReLU on the staged input, 2 x 1 tiles
+    (2, 72, 136, (16, 64), (3, 3), False, False),    # W = 64: two 32-pixel segments per line, H != W, ragged input tile
+    (3, 192, 264, (32, 32), (3, 3), False, False),   # W = 32, 3 x 2 tiles, several row slices
+    (1, 128, 128, (3, 16, 16), (3, 3, 3), False, False),   # 3-D, T = 3
     # nine-tap 3 x 3 weight-gradient kernel (Cout > 64): the three line geometries of its footprint
     (5, 40, 136, (8, 8), (3, 3), False, False),      # W = 8: four lines per step + 2 halo lines of 10 rows
     (3, 72, 200, (16, 16), (3, 3), False, True),     # W = 16: two lines + 2, two in-channel tiles, ReLU

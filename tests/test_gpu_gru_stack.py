@@ -155,31 +155,53 @@ def _stack_ws():
 
 @pytest.mark.parametrize("case", PROD, ids=lambda c: f"T{c[0]}B{c[1]}S{c[2]}h{c[4][0]}{'s' if c[6] else ''}{'i' if c[7] else ''}")
 def test_production_schedule_at_benchmark_size(case, monkeypatch):
-    """The four generator ConvGRUs at their real widths and B = 64 under the production split-K policy against the layer-by-layer
-    path (same bounds as the WIDE cases).  Also: every split-K ticket is back at zero, and the slab workspace the sizing query
-    asked for is EXACTLY the largest slab cursor a launched group used (an over- or under-sized workspace means the dry run
-    and the launch walked different schedules -- the round-5 slab overrun faulted only in the full step)."""
+    """The four generator ConvGRUs at their real widths and B = 64:
+      * the grouped launches with the per-layer path's split-K factors are BIT-EQUAL to the layer-by-layer path at this size too
+        (states, input gradient, initial-state gradients; weight gradients of these wide layers have no atomics: equal as well);
+      * the production plans (plan_splits: factors chosen from the tile counts, i.e. from B) against the layer-by-layer path at the
+        WIDE cases' bounds -- where 48 steps of bf16 BPTT amplify a change of fp32 summation order beyond them (measured: the layer
+        path against ITSELF with other split-K factors moves `cells.2.update_gate.weight` by 2.4e-2 at T = 48, S = 4), the bound
+        of a tensor is 1.5 x that yardstick;
+      * every split-K ticket is back at zero, and the slab workspace the sizing query asked for is EXACTLY the largest slab cursor
+        a launched group used (the round-5 slab overrun faulted only in the full step)."""
     from dvd_gan_amd import functional as Fn
     from dvd_gan_amd import lib as L
     gru, x, gys, h0s = _build(case)
+    dev = torch.device(DEV, torch.cuda.current_device())
     monkeypatch.setattr(Fn, "GRU_STACK", True)
     L.reset_gru_tickets()
     _stack_ws()
     new = _run(gru, case, x, gys, h0s, all_layers=False)
     sized, used = _stack_ws()
-    assert int(L.gru_tickets(torch.device(DEV, torch.cuda.current_device())).abs().sum()) == 0
+    assert int(L.gru_tickets(dev).abs().sum()) == 0
     assert sized > 0, "the production plan of a benchmark-sized stack splits no member at all?"
     assert used == sized, (used, sized)
+    # the same grouped kernels with the layer path's factors: bit-equal
+    monkeypatch.setattr(Fn, "GRU_COMBINE_MAX", 8)
+    monkeypatch.setattr(Fn, "GRU_STACK_LAYER_POLICY", 1)
+    pol = _run(gru, case, x, gys, h0s, all_layers=False)
+    assert int(L.gru_tickets(dev).abs().sum()) == 0
     monkeypatch.setattr(Fn, "GRU_STACK", False)
     old = _run(gru, case, x, gys, h0s, all_layers=False)
+    for l, (a, b) in enumerate(zip(pol["ys"], old["ys"])):
+        assert torch.equal(a, b), f"layer {l}: states differ (rel {_rel(a, b):.3e})"
+    assert torch.equal(pol["dx"], old["dx"])
+    for a, b in zip(pol["dh0"], old["dh0"]):
+        assert torch.equal(a, b)
+    for (k, _), a, b in zip(gru.named_parameters(), pol["dw"], old["dw"]):
+        assert _rel(a, b) < 1e-6, (k, _rel(a, b))
+    # yardstick: the layer path with other split-K factors (a different, equally valid fp32 summation order)
+    monkeypatch.setattr(Fn, "GRU_NS_CAP", 1)
+    alt = _run(gru, case, x, gys, h0s, all_layers=False)
+    yard = lambda key, i=None: _rel(alt[key], old[key]) if i is None else _rel(alt[key][i], old[key][i])
     for l, (a, b) in enumerate(zip(new["ys"], old["ys"])):
         assert torch.isfinite(a).all()
-        assert _rel(a, b) < 4e-3, (l, _rel(a, b))
-    assert _rel(new["dx"], old["dx"]) < 1e-2
-    for a, b in zip(new["dh0"], old["dh0"]):
-        assert _rel(a, b) < 1e-2
-    for (k, _), a, b in zip(gru.named_parameters(), new["dw"], old["dw"]):
-        assert _rel(a, b) < 1e-2, (k, _rel(a, b))
+        assert _rel(a, b) < max(4e-3, 1.5 * yard("ys", l)), (l, _rel(a, b), yard("ys", l))
+    assert _rel(new["dx"], old["dx"]) < max(1e-2, 1.5 * yard("dx"))
+    for i, (a, b) in enumerate(zip(new["dh0"], old["dh0"])):
+        assert _rel(a, b) < max(1e-2, 1.5 * yard("dh0", i))
+    for i, ((k, _), a, b) in enumerate(zip(gru.named_parameters(), new["dw"], old["dw"])):
+        assert _rel(a, b) < max(1e-2, 1.5 * yard("dw", i)), (k, _rel(a, b), yard("dw", i))
 
 
 @pytest.mark.parametrize("S,shared", [(4, True), (8, False)], ids=["gru0", "gru1"])
