@@ -4,6 +4,7 @@
 #include "conv_common.h"
 #include "prof.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -332,6 +333,10 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgK p) {
 template <int WM, int KW, bool RELU, bool UP2 = false, int NH = 2>
 __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     constexpr int NWAVE = WM * NH, NTt = NWAVE * 64, BMc = WM * 64, BNc = NH * 32;
+    // round 6: per-thread-constant input addresses (see the loader set-up).  Measured per tile (tools/conv_microbench.py wgrad, interleaved):
+    // 3 taps +1...4 % (8-wave tiles), +11 % (64-channel tile); 5 taps on the 128 x 128 tile +1.5 %; 5 taps on the 256 x 64 tile -4.5 %
+    // (its staggered halves lose their balance) -> that tile keeps the round-5 form.
+    constexpr bool FASTADDR = !UP2 && (KW == 3 || NH == 4);
     constexpr int RSA = BMc * 2 + 64;
     constexpr int TA_BYTES = 32 * RSA;
     constexpr int XROWS = KW == 5 ? 64 : 48, XHALF = XROWS * 64, TB_BYTES = NH * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows; W = 4: 8 lines x 8 (6) rows
@@ -339,7 +344,11 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     constexpr int SUB = TA_BYTES + TB_BYTES, STAGE = NS * SUB;
     constexpr int EPIB = NWAVE * 32 * 32 * 4;
     constexpr int REDB = NTt * 8 * 4;                            // bias partial sums
-    constexpr int LDSB = 2 * STAGE > EPIB ? (2 * STAGE > REDB ? 2 * STAGE : REDB) : (EPIB > REDB ? EPIB : REDB);
+    // 8-wave tiles sit at the 256-register limit: their bias column sums live in an LDS table behind the stage buffers (ds_add_f32 on
+    // the thread's own slots, same order of additions as the register form) instead of eight registers held through the main loop
+    constexpr bool BLDS = NWAVE == 8 && FASTADDR;
+    constexpr int LDSB0 = 2 * STAGE > EPIB ? (2 * STAGE > REDB ? 2 * STAGE : REDB) : (EPIB > REDB ? EPIB : REDB);
+    constexpr int LDSB = LDSB0 + (BLDS ? REDB : 0);
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / NH, wn = wave % NH;
@@ -391,6 +400,19 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     int xseg[NXL], xj[NXL], xdst[NXL];
     unsigned xcb[NXL];
     bool xcv[NXL];
+    // round 6 (not UP2): a sub-step starts at a multiple of 32 pixels -- whole lines (W <= 32: 32 / W of them, starting at a line that
+    // is a multiple of that; two whole frames when the frame is 4 x 4) or one 32-pixel segment of a line -- so the input row of chunk i is
+    // mk + (a per-thread constant), and only its validity depends on where the sub-step sits in the frame: (y + xya) in [0, H),
+    // (x0 + xxa) in [0, W).  Rebuilding line / column / frame of every chunk from mk cost ~13 VALU per chunk: 3.4 VALU per MFMA on the
+    // 3-tap tiles, which are bound by instruction issue (7.5 non-MFMA instructions per MFMA and wave, two waves per SIMD).
+    // At most ONE of the two checks is per thread: W > 32 -> the step is one line (every chunk has the same line offset: the line
+    // check is wave-uniform, the column check per thread); W <= 32 -> x0 = 0 (the column check is a per-thread constant, folded
+    // into xcv; the line check per thread).  xa = the per-thread addend of the remaining check.
+    int xa[NXL];
+    unsigned xld[NXL];
+    const bool twofr = (32 >> logsegw) > p.H;                    // 4 x 4 frames: the step's eight lines span two frames (y = x0 = 0)
+    const bool wide = p.W > 32;
+    const unsigned ldx2 = (unsigned)p.ldx * 2, ldy2 = (unsigned)p.ldy * 2;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
         const int q = tid + i * NTt, row = q / CPX, c8 = q % CPX;
@@ -400,9 +422,43 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
         xcv[i] = row < frows && cx < p.C;
         xcb[i] = (unsigned)cx * 2;
         xdst[i] = q < XROWS * CPX ? (c8 >> 2) * XHALF + row * 64 + (c8 & 3) * 16 : -1;
+        if constexpr (FASTADDR) {
+            const int fo = twofr ? xseg[i] >> p.logH : 0, yl = twofr ? xseg[i] & (p.H - 1) : xseg[i];
+            const int xya = yl + dyl, xxa = xj[i] - pad;
+            xld[i] = (unsigned)((fo << (p.logW + p.logH)) + (xya << p.logW) + xxa) * ldx2 + xcb[i];   // (wraps for negative deltas; the sum with the uniform part is exact)
+            xa[i] = wide ? xxa : xya;
+            if (!wide) xcv[i] = xcv[i] && (unsigned)xxa < (unsigned)p.W;
+        }
     }
+    const unsigned yld = (unsigned)rra * ldy2 + (unsigned)cy * 2;
+    const int dt_rows = p.kt > 1 ? dtl << (p.logW + p.logH) : 0;
     u32x4 ra[NS][NPA], rb[NS][NXL];
     auto gload1 = [&](int mk, u32x4 (&ra)[NPA], u32x4 (&rb)[NXL]) __attribute__((always_inline)) {
+        if constexpr (FASTADDR) {
+            // slices and M are multiples of 32 rows: a sub-step is inside the slice or outside it as a whole
+            const bool ytok = mk < m_end;
+            bool tok = ytok;
+            if (p.kt > 1) {
+                const int tt = (mk >> (p.logW + p.logH)) % p.T + dtl;
+                tok = tok && (unsigned)tt < (unsigned)p.T;
+            }
+            const unsigned yoff = (unsigned)(mk - m_begin) * ldy2, xoff = (unsigned)(mk + dt_rows - xbase_row) * ldx2;
+            const int x0 = mk & (p.W - 1), y = twofr ? 0 : (mk >> p.logW) & (p.H - 1);
+            if (wide) tok = tok && (unsigned)(y + dyl) < (unsigned)p.H;
+            const int sval = wide ? x0 : y;
+            const unsigned slim = wide ? p.W : p.H;
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                const unsigned off = (cyv && ytok) ? yld + yoff + (unsigned)(i * RPPA) * ldy2 : 0xffffffffu;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) {
+                const bool ok = xcv[i] && tok && (unsigned)(sval + xa[i]) < slim;
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xld[i] + xoff : 0xffffffffu, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int m = mk + rra + i * RPPA;
@@ -452,6 +508,11 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     const int nshare = spread ? KW * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
     int bphase = 0;                                              // share of the next sub-step to be stored
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float* btab = reinterpret_cast<float*>(&smem[LDSB0]) + tid;       // BLDS: [8][NTt] floats, slot k of this thread at btab[k * NTt]
+    if (BLDS && do_bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) btab[k * NTt] = 0.f;
+    }
     auto lstore1 = [&](char* st, const u32x4 (&ra)[NPA], const u32x4 (&rb)[NXL]) __attribute__((always_inline)) {
         const bool mine = do_bias && bphase == myshare;          // wave-uniform
         if (++bphase == nshare) bphase = 0;
@@ -459,10 +520,15 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
         for (int i = 0; i < NPA; ++i) {
             *reinterpret_cast<u32x4*>(st + (rra + i * RPPA) * RSA + cka * 16) = ra[i];
             if (mine) {
-                bs[0] += __uint_as_float(ra[i].x << 16); bs[1] += __uint_as_float(ra[i].x & 0xffff0000u);
-                bs[2] += __uint_as_float(ra[i].y << 16); bs[3] += __uint_as_float(ra[i].y & 0xffff0000u);
-                bs[4] += __uint_as_float(ra[i].z << 16); bs[5] += __uint_as_float(ra[i].z & 0xffff0000u);
-                bs[6] += __uint_as_float(ra[i].w << 16); bs[7] += __uint_as_float(ra[i].w & 0xffff0000u);
+                const float v[8] = {__uint_as_float(ra[i].x << 16), __uint_as_float(ra[i].x & 0xffff0000u),
+                                    __uint_as_float(ra[i].y << 16), __uint_as_float(ra[i].y & 0xffff0000u),
+                                    __uint_as_float(ra[i].z << 16), __uint_as_float(ra[i].z & 0xffff0000u),
+                                    __uint_as_float(ra[i].w << 16), __uint_as_float(ra[i].w & 0xffff0000u)};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if constexpr (BLDS) __hip_atomic_fetch_add(btab + k * NTt, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else bs[k] += v[k];
+                }
             }
         }
 #pragma unroll
@@ -563,13 +629,15 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     }
     if (do_bias) {
         float* red = reinterpret_cast<float*>(&smem[0]);
+        if constexpr (!BLDS) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
+            for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
+        }
         __syncthreads();
         if (tid < CPRA) {
             for (int k = 0; k < 8; ++k) {
                 float a = 0.f;
-                for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
+                for (int r = 0; r < RPPA; ++r) a += BLDS ? btab[k * NTt + r * CPRA] : red[(r * CPRA + tid) * 8 + k];
                 const int co = co0 + tid * 8 + k;
                 if (spread) p.wsb[((size_t)bz * gridDim.x + bx) * BMc + tid * 8 + k] = a;      // partial of (slice, workgroup)
                 else if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
@@ -611,6 +679,27 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
         }
 }
 
+// compile-time loop (the unit index of conv_wgrad_row4_kernel must be a constant expression: it selects the register class of an
+// accumulator tile)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// v_mfma_f32_32x32x16_bf16 with the accumulator tile pinned to the AGPR half (V = false) or the VGPR half (V = true) of the unified
+// register file.  hipcc selects ONE form for every MFMA builtin of a function -- all accumulators in AGPRs (at most 256 registers =
+// 16 tiles) once the function may use more than 256 registers -- so a wave that owns 24 tiles spills 300 registers through the
+// builtin (measured).  As inline assembly sixteen tiles sit in a0..a255 and eight in VGPRs.  The compiler still tracks the operands
+// (s_waitcnt for the fragments' LDS reads); what it cannot see is the MFMA's result latency: the kernel never reads an accumulator
+// inside the loop except as the C operand of a later MFMA on the same tile (>= 4 MFMAs later), and pads before its epilogue.
+template <bool V>
+__device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    if constexpr (V) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 // ============================================================================ backward-weight, one filter row, ONE WAVE PER SIMD (round 6)
 // The 8-wave row kernel above is held by its LDS traffic on 3-tap filters (pipe busy 0.47-0.52 with clock headroom,
 // profiles/r05_pmc_wgrad.json): 229 staged bytes and 1.67 transposing reads per MFMA.  More MFMAs per staged byte need a larger
@@ -627,7 +716,10 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
 //     behind it already read the first fragments of sub-step s+1, so the matrix pipe is fed across the barrier;
 //   * every LDS / VMEM operation is pinned between two MFMA units (sched_barrier), ~1 staging operation per unit.
 // Same LDS images, loaders, slice workspace, bias shares and reduce kernels as conv_wgrad_row_kernel (no x2-upsampled input).
-template <int KW, int AW, int BW, int WCO, int WCI, bool RELU>
+#ifndef DVD_EXP_ROW4                  // timing-only experiment builds (wrong results): 1 = no global loads, 2 = no LDS stores, 4 = no barrier
+#define DVD_EXP_ROW4 0
+#endif
+template <int KW, int AW, int BW, int WCO, int WCI, bool RELU, int DEPTH = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     static_assert(WCO * WCI == 4, "four waves, one per SIMD");
     constexpr int NTt = 256, BMc = WCO * AW * 32, NHB = WCI * BW, BNc = NHB * 32;
@@ -636,7 +728,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     constexpr int XROWS = KW == 5 ? 64 : 48, XHALF = XROWS * 64, TB_BYTES = NHB * XHALF;
     constexpr int SUB = TA_BYTES + TB_BYTES;
     constexpr int EPIB = 4 * 32 * 32 * 4, REDB = NTt * 8 * 4;
-    constexpr int LDSB = 3 * SUB > EPIB ? (3 * SUB > REDB ? 3 * SUB : REDB) : (EPIB > REDB ? EPIB : REDB);
+    constexpr int LDSB0 = 3 * SUB > EPIB ? (3 * SUB > REDB ? 3 * SUB : REDB) : (EPIB > REDB ? EPIB : REDB);
+    constexpr int LDSB = LDSB0 + REDB;                           // + the bias column sums [8][256] (LDS table: no registers held through the loop)
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WCI, wn = wave % WCI;
@@ -685,44 +778,73 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     constexpr int CPX = NHB * 4;
     constexpr int NXL = (XROWS * CPX + NTt - 1) / NTt;
     constexpr int NOPS = NPA + NXL;
-    int xseg[NXL], xj[NXL], xdst[NXL];
-    unsigned xcb[NXL];
+    // Addresses.  A sub-step starts at a multiple of 32 pixels: it covers whole lines (W <= 32: 32 / W of them, starting at a line that
+    // is a multiple of that; two whole frames when the frame is 4 x 4) or one 32-pixel segment of a line, so the input row a thread
+    // fetches for chunk i is   mk + (a per-thread constant)   -- the first row of the sub-step plus the chunk's position in the
+    // footprint -- and only its validity depends on where the sub-step sits in the frame: (y + xya) in [0, H) and (x0 + xxa) in [0, W).
+    // (The 8-wave kernel rebuilds line / column / frame of every chunk from mk: ~14 VALU per chunk; here 6.)  Slices and M are
+    // multiples of 32 rows, so a sub-step is inside the slice or outside it as a whole (`tok`, wave-uniform).
+    constexpr bool XFULL = NXL * NTt == XROWS * CPX;             // every thread owns NXL chunks of the footprint image
+    // At most ONE of the two checks is per thread: W > 32 -> the step is one line (the line check is wave-uniform, the column check
+    // per thread); W <= 32 -> x0 = 0 (the column check is a per-thread constant, folded into xv; the line check per thread).
+    int xa[NXL];
+    static_assert(NTt % CPX == 0, "chunk i of a thread sits NTt / CPX footprint rows below chunk i - 1");
+    const int xdst0 = ((tid % CPX) >> 2) * XHALF + (tid / CPX) * 64 + ((tid % CPX) & 3) * 16;      // chunk i: + i * (NTt / CPX) * 64 (an immediate)
+    unsigned xld[NXL];
+    bool xv[NXL];
+    const bool twofr = (32 >> logsegw) > p.H;                    // 4 x 4 frames: the step's eight lines span two frames (y = x0 = 0)
+    const bool wide = p.W > 32;
+    const unsigned ldx2 = (unsigned)p.ldx * 2, ldy2 = (unsigned)p.ldy * 2;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
         const int q = tid + i * NTt, row = q / CPX, c8 = q % CPX;
-        xseg[i] = row / fpr;
-        xj[i] = row - xseg[i] * fpr;
+        const int seg = row / fpr, j = row - seg * fpr;
         const int cx = ci0 + c8 * 8;
-        xcb[i] = (row < frows && cx < p.C) ? (unsigned)cx * 2 : 0xffffffffu;            // 0xffffffff: never a valid chunk
-        xdst[i] = q < XROWS * CPX ? (c8 >> 2) * XHALF + row * 64 + (c8 & 3) * 16 : -1;
+        const int fo = twofr ? seg >> p.logH : 0, yl = twofr ? seg & (p.H - 1) : seg;
+        const int xya = yl + dyl, xxa = j - pad;
+        xa[i] = wide ? xxa : xya;
+        xv[i] = row < frows && cx < p.C && (wide || (unsigned)xxa < (unsigned)p.W);
+        const int delta = (fo << (p.logW + p.logH)) + (xya << p.logW) + xxa;
+        xld[i] = (unsigned)delta * ldx2 + (unsigned)cx * 2;      // (wraps for negative deltas; the sum with the uniform part is exact)
     }
-    u32x4 R[NOPS];
-    struct Geo { int x0, y, frow0; bool tok; };
+    const unsigned yld = (unsigned)rra * ldy2 + (unsigned)cy * 2;
+    const int dt_rows = p.kt > 1 ? dtl << (p.logW + p.logH) : 0;
+    u32x4 R[DEPTH][NOPS];      // staging registers: set d holds the chunks of every DEPTH-th sub-step, loaded DEPTH sub-steps before they are stored
+    struct Geo { int sval; unsigned xoff, yoff; bool tok, ytok; };
+    const unsigned slim = wide ? p.W : p.H;
+    // geometry of the sub-step that starts at pixel mk, in four pieces (wave-uniform scalar work: inside the main loop each piece
+    // sits in a slot of its own -- as one block it was a 25-instruction bubble in front of one MFMA)
+    auto geo_part = [&](Geo& g, int mk, int part) __attribute__((always_inline)) {
+        if (part == 0) {
+            const int x0 = mk & (p.W - 1), y = twofr ? 0 : (mk >> p.logW) & (p.H - 1);
+            g.sval = wide ? x0 : y;
+            g.ytok = mk < m_end;
+            g.tok = g.ytok && (!wide || (unsigned)(y + dyl) < (unsigned)p.H);
+        } else if (part == 1) {
+            if (p.kt > 1) {
+                const int tt = (mk >> (p.logW + p.logH)) % p.T + dtl;
+                g.tok = g.tok && (unsigned)tt < (unsigned)p.T;
+            }
+        } else if (part == 2) {
+            g.xoff = (unsigned)(mk + dt_rows - xbase_row) * ldx2;
+        } else {
+            g.yoff = (unsigned)(mk - m_begin) * ldy2;
+        }
+    };
     auto geo = [&](int mk) __attribute__((always_inline)) -> Geo {
         Geo g;
-        g.x0 = mk & (p.W - 1); g.y = (mk >> p.logW) & (p.H - 1);
-        g.frow0 = mk - (g.y << p.logW) - g.x0;
-        g.tok = mk < m_end;
-        if (p.kt > 1) {
-            const int tt = (mk >> (p.logW + p.logH)) % p.T + dtl;
-            g.tok = g.tok && (unsigned)tt < (unsigned)p.T;
-            g.frow0 += dtl << (p.logW + p.logH);
-        }
+#pragma unroll
+        for (int part = 0; part < 4; ++part) geo_part(g, mk, part);
         return g;
     };
-    auto load_op = [&](int op, int mk, const Geo& g) __attribute__((always_inline)) {
+    auto load_op = [&](int op, const Geo& g, u32x4 (&R)[NOPS]) __attribute__((always_inline)) {
         if (op < NPA) {
-            const int m = mk + rra + op * RPPA;
-            const unsigned off = (cyv && m < m_end) ? (unsigned)(m - m_begin) * ((unsigned)p.ldy * 2) + cy * 2 : 0xffffffffu;
+            const unsigned off = (cyv && g.ytok) ? yld + g.yoff + (unsigned)(op * RPPA) * ldy2 : 0xffffffffu;
             R[op] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
         } else {
             const int i = op - NPA;
-            const int lf = g.y + xseg[i], fo = lf >> p.logH;
-            const int yy = (lf & (p.H - 1)) + dyl;
-            const int xx = g.x0 + xj[i] - pad;
-            const bool ok = xcb[i] != 0xffffffffu && g.tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            const int row = g.frow0 + (fo << (p.logW + p.logH)) + (yy << p.logW) + xx;
-            const unsigned off = ok ? (unsigned)(row - xbase_row) * ((unsigned)p.ldx * 2) + xcb[i] : 0xffffffffu;
+            const bool ok = xv[i] && g.tok && (unsigned)(g.sval + xa[i]) < slim;
+            const unsigned off = ok ? xld[i] + g.xoff : 0xffffffffu;
             R[op] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
         }
     };
@@ -731,19 +853,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     const bool do_bias = p.dbias != nullptr && dtl == 0 && (spread || (dyl == 0 && tci == 0));
     const int nshare = spread ? KW * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
     int bphase = 0;
-    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto store_op = [&](int op, char* st, bool mine) __attribute__((always_inline)) {
+    float* btab = reinterpret_cast<float*>(&smem[LDSB0]) + tid;       // [8][256] floats, slot k of this thread at btab[k * NTt]
+    if (do_bias) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) btab[k * NTt] = 0.f;
+    }
+    auto store_op = [&](int op, char* st, bool mine, const u32x4 (&R)[NOPS]) __attribute__((always_inline)) {
         if (op < NPA) {
             *reinterpret_cast<u32x4*>(st + (rra + op * RPPA) * RSA + cka * 16) = R[op];
-            if (mine) {
-                bs[0] += __uint_as_float(R[op].x << 16); bs[1] += __uint_as_float(R[op].x & 0xffff0000u);
-                bs[2] += __uint_as_float(R[op].y << 16); bs[3] += __uint_as_float(R[op].y & 0xffff0000u);
-                bs[4] += __uint_as_float(R[op].z << 16); bs[5] += __uint_as_float(R[op].z & 0xffff0000u);
-                bs[6] += __uint_as_float(R[op].w << 16); bs[7] += __uint_as_float(R[op].w & 0xffff0000u);
+            if (mine) {                                           // (the thread's own slots: ds_add_f32, same order of additions as a register sum)
+                const float v[8] = {__uint_as_float(R[op].x << 16), __uint_as_float(R[op].x & 0xffff0000u),
+                                    __uint_as_float(R[op].y << 16), __uint_as_float(R[op].y & 0xffff0000u),
+                                    __uint_as_float(R[op].z << 16), __uint_as_float(R[op].z & 0xffff0000u),
+                                    __uint_as_float(R[op].w << 16), __uint_as_float(R[op].w & 0xffff0000u)};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(btab + k * NTt, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
             const int i = op - NPA;
-            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(st + TA_BYTES + xdst[i]) = RELU ? relu16_bf16(R[op]) : R[op];
+            if (XFULL || tid + i * NTt < XROWS * CPX)
+                *reinterpret_cast<u32x4*>(st + TA_BYTES + xdst0 + i * (NTt / CPX) * 64) = RELU ? relu16_bf16(R[op]) : R[op];
         }
     };
     typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -756,104 +885,118 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
         s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, f);
     };
-    int xoffs[2][2];                                             // [k half][lo / hi 4-row block] of this wave's first 32-channel block
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-            const int pk = kb * 16 + frow + hl * 4;
-            const int fr = (pk >> logsegw) * fpr + (pk & (segw - 1));
-            xoffs[kb][hl] = TA_BYTES + wn * BW * XHALF + fr * 64 + fcol2;
-        }
+    // B fragment addresses: the lane's pixel of k half kb / 4-row block hl is pk = kb * 16 + frow + hl * 4; its footprint row
+    // (pk >> logsegw) * fpr + (pk & (segw - 1)) is  row(frow) + kb * KBROWS + hl * 4  with a wave-uniform KBROWS (frow + 4 < 16 stays
+    // inside the lane's line segment for every segment width >= 8; 4-wide segments: frow and frow + 4 are one line apart)
+    const int fr0 = (frow >> logsegw) * fpr + (frow & (segw - 1));
+    const int hlstep = (segw >= 8 ? 4 : fpr) * 64;                                            // bytes from the lo to the hi 4-row block
+    const int kbstep = ((16 >> logsegw) * fpr + (16 & (segw - 1))) * 64;                      // bytes from k half 0 to k half 1
+    const int xoff0 = TA_BYTES + wn * BW * XHALF + fr0 * 64 + fcol2;
     const int aoff = frow * RSA + fcol2 + (wm * AW * 32) * 2;
     constexpr int UPK = KW * BW, NU = 2 * UPK;                   // units per k half / per sub-step; unit = (k half, tap, in-channel block)
-    constexpr int UB = NU >= 8 ? NU - 3 : NU - 2;                // the sub-step's barrier sits in front of unit UB
-    static_assert(UB >= UPK, "the next sub-step's A fragments reuse the first k half's registers");
-    bf16x8 fa[2][AW], fb[3];
+    constexpr bool PIN = AW * BW * KW > 16;                      // more accumulator tiles than the AGPR half holds: see mfma_pinned
+    constexpr int UB = NU - 2;                                   // the sub-step's barrier sits in front of unit UB (two units of fragments read ahead)
+    // A fragments: ONE register set.  fa[a] is re-read for the next k half in the slot right after its last MFMA of this one
+    // (AW - 1 slots, ~100 cycles, before its first use there) -- a second set would cost the 16 registers the second staging set needs.
+    bf16x8 fa[AW], fb[3];
     auto ldA = [&](const char* st, int kb, int a) __attribute__((always_inline)) {
         const char* pz = st + aoff + kb * 16 * RSA + a * 64;
-        fa[kb][a] = tr2(pz, pz + 4 * RSA);
+        fa[a] = tr2(pz, pz + 4 * RSA);
     };
     auto ldB = [&](const char* st, int u, int slot) __attribute__((always_inline)) {
         const int kb = u / UPK, t = (u % UPK) / BW, b = u % BW;
-        fb[slot] = tr2(st + xoffs[kb][0] + t * 64 + b * XHALF, st + xoffs[kb][1] + t * 64 + b * XHALF);
+        const char* pz = st + xoff0 + kb * kbstep + t * 64 + b * XHALF;
+        fb[slot] = tr2(pz, pz + hlstep);
     };
     if (m_begin < m_end) {
-        // prologue: sub-step 0 into ring slot 0, sub-step 1 into the registers
+        // prologue: sub-step 0 into ring slot 0, sub-steps 1 .. DEPTH into the register sets
         {
             const Geo g0 = geo(m_begin);
 #pragma unroll
-            for (int op = 0; op < NOPS; ++op) load_op(op, m_begin, g0);
+            for (int op = 0; op < NOPS; ++op) load_op(op, g0, R[0]);
             const bool mine = do_bias && bphase == myshare;
             if (++bphase == nshare) bphase = 0;
 #pragma unroll
-            for (int op = 0; op < NOPS; ++op) store_op(op, &smem[0], mine);
-            const Geo g1 = geo(m_begin + 32);
+            for (int op = 0; op < NOPS; ++op) store_op(op, &smem[0], mine, R[0]);
 #pragma unroll
-            for (int op = 0; op < NOPS; ++op) load_op(op, m_begin + 32, g1);
+            for (int d = 0; d < DEPTH; ++d) {
+                const Geo g1 = geo(m_begin + 32 * (d + 1));
+#pragma unroll
+                for (int op = 0; op < NOPS; ++op) load_op(op, g1, R[d]);
+            }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
 #pragma unroll
-            for (int a = 0; a < AW; ++a) ldA(&smem[0], 0, a);
+            for (int a = 0; a < AW - 1; ++a) ldA(&smem[0], 0, a);       // (fa[AW - 1]: slot (0, 0) of every sub-step)
             ldB(&smem[0], 0, 0);
             ldB(&smem[0], 1, 1);
         }
         char* rd = &smem[0];
         char* nx = &smem[SUB];
         char* fr_ = &smem[2 * SUB];
-        for (int mk = m_begin; mk < m_end; mk += 32) {
-            const Geo gl = geo(mk + 64);
+        // One wave per SIMD: the matrix pipe only stays busy if the wave's other instructions sit BETWEEN its MFMAs (32 cycles each,
+        // ~5 issue slots), so every MFMA is a slot of its own (sched_barrier after each) with a fixed share of the sub-step's LDS reads,
+        // LDS stores, address arithmetic and global loads in front of it.  (First form: four MFMAs back to back per unit, then the
+        // unit's ~20 other instructions with the pipe idle -- pipe busy 0.56.)  Slot a of unit u:
+        //   a = 0: B fragment of unit u + 2;  a = 1: LDS stores of the unit's staging chunks;  a = 2 (and 3 behind the barrier): A
+        //   fragments;  a = AW - 1: address + global load of the unit's staging chunks, and once per sub-step the next geometry.
+        static_assert(AW == 4, "slot plan written for four A fragments per wave");
+        Geo gl = geo(m_begin + 32 * (DEPTH + 1));
+        for (int mk0 = m_begin; mk0 < m_end; mk0 += 32 * DEPTH) {
+          static_for<0, DEPTH>([&](auto D_) __attribute__((always_inline)) {       // (an odd tail runs one sub-step of zeros)
+            constexpr int dset = decltype(D_)::value;
+            const int mk = mk0 + 32 * dset;
             const bool mine = do_bias && bphase == myshare;              // share of the sub-step being stored (mk + 32)
             if (++bphase == nshare) bphase = 0;
+            Geo gn = gl;
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                // staging: chunk ops spread over the units in front of the barrier
-#pragma unroll
-                for (int op = 0; op < NOPS; ++op)
-                    if ((op * UB) / NOPS == u) {
-                        store_op(op, nx, mine);
-                        load_op(op, mk + 64, gl);
-                    }
-                if (u == UB) {
+            static_for<0, NU * AW>([&](auto S_) __attribute__((always_inline)) {
+                constexpr int s = decltype(S_)::value, u = s / AW, a = s % AW;
+                constexpr int kb = u / UPK, t = (u % UPK) / BW, b = u % BW;
+                if constexpr (u == UB && a == 0) {
                     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's stores of sub-step s+1 are in the LDS
-                    __builtin_amdgcn_s_barrier();
+                    if (!(DVD_EXP_ROW4 & 4)) __builtin_amdgcn_s_barrier();
                 }
-                // B fragment two units ahead (the last two units reach into the next sub-step)
-                if (u + 2 < NU) ldB(rd, u + 2, (u + 2) % 3);
-                else ldB(nx, u + 2 - NU, (u + 2) % 3);
-                // A fragments: second k half during the first, the next sub-step's first k half behind the barrier
-                if (u < UPK) {
-#pragma unroll
-                    for (int a = 0; a < AW; ++a)
-                        if ((a * UPK) / AW == u) ldA(rd, 1, a);
-                } else if (u >= UB) {
-#pragma unroll
-                    for (int a = 0; a < AW; ++a)
-                        if ((a * (NU - UB)) / AW == u - UB) ldA(nx, 0, a);
+                if constexpr (a == 0) {                                  // B fragment two units ahead (the last two reach into the next sub-step)
+                    if (u + 2 < NU) ldB(rd, u + 2, (u + 2) % 3);
+                    else ldB(nx, u + 2 - NU, (u + 2) % 3);
                 }
-                {
-                    const int kb = u / UPK, t = (u % UPK) / BW, b = u % BW;
+                if constexpr (a == 1) {
 #pragma unroll
-                    for (int a = 0; a < AW; ++a)
-                        acc[a][b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][a], fb[u % 3], acc[a][b][t], 0, 0, 0);
+                    for (int op = 0; op < NOPS; ++op)
+                        if ((op * UB) / NOPS == u && !(DVD_EXP_ROW4 & 2)) store_op(op, nx, mine, R[dset]);
                 }
+                // A fragment a - 1 of the next k half, right behind its last MFMA of this one (the next sub-step's come from `nx`, behind the barrier)
+                if constexpr (u == UPK - 1 && a >= 1) ldA(rd, 1, a - 1);
+                if constexpr (u == UPK && a == 0) ldA(rd, 1, AW - 1);
+                if constexpr (u == NU - 1 && a >= 1) ldA(nx, 0, a - 1);
+                if constexpr (u == 0 && a == 0) ldA(rd, 0, AW - 1);
+                if constexpr (a == AW - 1) {
+#pragma unroll
+                    for (int op = 0; op < NOPS; ++op)
+                        if ((op * UB) / NOPS == u && !(DVD_EXP_ROW4 & 1)) load_op(op, gl, R[dset]);
+                }
+                // geometry of the next sub-step's loads, a piece per slot (the slots behind the barrier carry little else)
+                if constexpr (u == UB - 1 && a == AW - 1) geo_part(gn, mk + 32 * (DEPTH + 2), 0);
+                if constexpr (u == UB && a >= 1) geo_part(gn, mk + 32 * (DEPTH + 2), a);
+                if constexpr (PIN) mfma_pinned<((a * BW + b) * KW + t >= 16)>(acc[a][b][t], fa[a], fb[u % 3]);
+                else acc[a][b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[u % 3], acc[a][b][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
+            gl = gn;
             char* t_ = rd; rd = nx; nx = fr_; fr_ = t_;
+          });
         }
         __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): two sub-steps of prefetch are still in flight
+        if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (inline assembly: latency unknown to hipcc)
         __syncthreads();
     }
     if (do_bias) {
-        float* red = reinterpret_cast<float*>(&smem[0]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) red[tid * 8 + k] = bs[k];
         __syncthreads();
         if (tid < CPRA) {
             for (int k = 0; k < 8; ++k) {
                 float a = 0.f;
-                for (int r = 0; r < RPPA; ++r) a += red[(r * CPRA + tid) * 8 + k];
+                for (int r = 0; r < RPPA; ++r) a += btab[k * NTt + r * CPRA];
                 const int co = co0 + tid * 8 + k;
                 if (spread) p.wsb[((size_t)bz * gridDim.x + bx) * BMc + tid * 8 + k] = a;
                 else if (co < p.Cout && a != 0.f) atomicAdd(p.dbias + co, a);
@@ -1049,11 +1192,19 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         // the two 4-wave workgroups per CU of the 64-channel form stay 3 % ahead
         const bool ci128 = (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64;      // 128-channel input tiles pad no further
         if (ta == 2 && d->kw == 5 && !d->up2 && ci128) tb = 2;
-#ifndef DVD_WG_ROW4
-#define DVD_WG_ROW4 1
+#ifndef DVD_WG_ROW4                    // 0 = 8-wave tiles only, 1 = the 128 x 128 one-wave-per-SIMD tile only, 2 = + the pinned 256 x 128 tile (default)
+#define DVD_WG_ROW4 2
+#endif
+#ifndef DVD_ROW4_DEPTH                 // staging depth of the 128 x 128 one-wave-per-SIMD tile (experiment knob)
+#define DVD_ROW4_DEPTH 2
 #endif
         // 3 taps (round 6): one wave per SIMD with the whole register file -- 256 x 128 (or 128 x 128) channel tiles, mode 2
-        if (DVD_WG_ROW4 && d->kw == 3 && !d->up2 && ci128 && ta >= 2) { mode = 2; tb = 2; if (DVD_WG_ROW4 == 1) ta = 2; }
+        // (needs a round of workgroups with >= 4096 rows each: 256 x 256 channels on 48 k rows ran 172 us against 101 on the 8-wave tile)
+        if (DVD_WG_ROW4 && d->kw == 3 && !d->up2 && ci128 && ta >= 2) {
+            const int t4 = DVD_WG_ROW4 == 1 ? 2 : ta;
+            const long long wgs = (long long)((d->Cout + t4 * 64 - 1) / (t4 * 64)) * ((d->Cin_real + 127) / 128) * d->kt * d->kh * (M / 4096);
+            if (wgs >= 224) { mode = 2; tb = 2; ta = t4; }
+        }
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
@@ -1157,8 +1308,8 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
                            else conv_wgrad_row4_kernel<3, 4, 2, 2, 2, false><<<grid, 256, 0, st>>>(p); }
             else
 #endif
-                         { if (d->relu_in) conv_wgrad_row4_kernel<3, 4, 1, 1, 4, true><<<grid, 256, 0, st>>>(p);
-                           else conv_wgrad_row4_kernel<3, 4, 1, 1, 4, false><<<grid, 256, 0, st>>>(p); }
+                         { if (d->relu_in) conv_wgrad_row4_kernel<3, 4, 1, 1, 4, true, DVD_ROW4_DEPTH><<<grid, 256, 0, st>>>(p);
+                           else conv_wgrad_row4_kernel<3, 4, 1, 1, 4, false, DVD_ROW4_DEPTH><<<grid, 256, 0, st>>>(p); }
         } else
         if (d->up2) { if (ta == 4) LAUNCH_ROW_UP(4); else if (ta == 2) LAUNCH_ROW_UP(2); else LAUNCH_ROW_UP(1); }
         else if (tb == 2) { if (d->kw == 5) LAUNCH_ROW_W(5); else LAUNCH_ROW_W(3); }
