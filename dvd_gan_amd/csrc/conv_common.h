@@ -46,6 +46,7 @@ struct ConvK {
     int nb32;                            // 32-column blocks per (tap, chunk) of the fragment-major image `wq`
     int nmajor;                          // tile order: consecutive workgroups (one XCD's run) share the N tile, not the M tile
     int pm;                              // > 0 (tap-by-tap kernel, small frames): GEMM rows in PIXEL-major order, pm = frames (see conv_igemm_kernel)
+    int pool2;                           // halo kernels: `out` / `mask` on the half-size grid, 2 x 2 sums of the result (dvd_conv_desc.pool2)
     size_t in_bytes; unsigned w_bytes;   // extents for the buffer descriptors (hardware zero-fill past them)
     int maxshift;                        // largest |tap shift| in rows
     GruEpi g;                            // optional fused ConvGRU gate epilogue (mode 0 = off)
@@ -433,6 +434,41 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x16 (&acc)[TM][
 #pragma unroll
     for (int k = 0; k < 8; ++k) bias8[k] = (p.bias && k < nvalid) ? p.bias[col + k] : 0.f;
     const bool has_mask = p.mask != nullptr;
+    if (p.pool2) {
+        // 2 x 2 sums onto the half-size grid (halo kernels: a 32-row sub-tile is two 16-pixel lines of the patch, i.e. eight whole
+        // 2 x 2 blocks; staged rows 2j, 2j + 1, 16 + 2j, 17 + 2j -> pooled pixel j = lane >> 3, eight columns per lane)
+        const long long lrow0 = row0 >> 2, lrows = (long long)(p.M >> 2) - lrow0;
+        const auto rmaskp = epi_rsrc(p.mask, lrow0, p.ldmask * esz, lrows);
+        const auto routp = epi_rsrc(p.out, lrow0, p.ldo * (p.out_f32 ? 4u : esz), lrows);
+#pragma unroll                                                           // (a runtime tm would index the accumulators dynamically: scratch for the whole kernel)
+        for (int tm = 0; tm < TM; ++tm) {
+            stage(tm);
+            const int base = rrow(tm * 4) - erow;                        // first pixel of the sub-tile's first line, row within the frame
+            const int y = base >> p.logW, x = base & (p.W - 1);
+            const int lr = (y >> 1) * (p.W >> 1) + (x >> 1) + erow;
+            const Raw8<T> mraw = bld8<T>(rmaskp, offs(lr, p.ldmask, esz, col, colv));
+            float v[8], m8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 4.f * bias8[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* src = ep + ((q >> 1) * 16 + 2 * erow + (q & 1)) * 64 + ecol;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+            }
+            unpack8(mraw, m8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = (has_mask && !(m8[k] > 0.f)) ? 0.f : v[k];
+                v[k] = (k < nvalid) ? v[k] : 0.f;
+            }
+            if (p.out_f32) bst8<float>(routp, offs(lr, p.ldo, 4, col, colv), v);
+            else bst8<T>(routp, offs(lr, p.ldo, esz, col, colv), v);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                          // the staged rows are consumed before the next sub-tile overwrites them
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     // the residual of a res_up2 conv lives on the half-size grid; its descriptor starts at the tile's first frame there
     const long long res_row0 = p.res_up2 ? (row0 / (p.H * p.W)) * ((p.H >> 1) * (p.W >> 1)) : row0;
     const auto rres = epi_rsrc(p.res, res_row0, p.ldres * esz, (p.res_up2 ? (long long)(p.M >> 2) : (long long)p.M) - res_row0);

@@ -727,7 +727,19 @@ static int conv_plan(const dvd_conv_desc* d, const GruEpi* g, ConvK& p, ConvPlan
             p.pm = F;
     }
     pl.M = M; pl.halo = halo; pl.thin = thin; pl.wide = wide; pl.big = big && !(smallf && d->W == 4); pl.smallf = smallf;
+    p.pool2 = d->pool2 != 0;
+    if (p.pool2 && (!halo || p.nsplit != 1 || g || d->ws || d->res || d->act != DVD_ACT_NONE || d->kt != 1 || d->T != 1 || d->up2))
+        return DVD_E_SHAPE;                   // (dvd_conv_pool2_ok: the 2 x 2 sums are an epilogue of the halo-staged kernels' patch tiles)
     return DVD_OK;
+}
+
+extern "C" int dvd_conv_pool2_ok(const dvd_conv_desc* d) {
+    if (!d || !d->pool2) return 0;
+    ConvK p; ConvPlan pl;
+    dvd_conv_desc t = *d;
+    static char dummy;
+    if (!t.out) t.out = &dummy;               // (a geometry query: the output may not exist yet)
+    return conv_plan(&t, nullptr, p, pl) == DVD_OK ? 1 : 0;
 }
 
 extern "C" int dvd_conv_forward_gru(const dvd_conv_desc* d, const GruEpi* g, void* stream) {

@@ -334,9 +334,9 @@ template <int WM, int KW, bool RELU, bool UP2 = false, int NH = 2>
 __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     constexpr int NWAVE = WM * NH, NTt = NWAVE * 64, BMc = WM * 64, BNc = NH * 32;
     // round 6: per-thread-constant input addresses (see the loader set-up).  Measured per tile (tools/conv_microbench.py wgrad, interleaved):
-    // 3 taps +1...4 % (8-wave tiles), +11 % (64-channel tile); 5 taps on the 128 x 128 tile +1.5 %; 5 taps on the 256 x 64 tile -4.5 %
-    // (its staggered halves lose their balance) -> that tile keeps the round-5 form.
-    constexpr bool FASTADDR = !UP2 && (KW == 3 || NH == 4);
+    // 3 taps +1...4 % (8-wave tiles), +11 % (64-channel tile); 5 taps on the 128 x 128 tile +1.5 % but two spilled registers;
+    // 5 taps on the 256 x 64 tile -4.5 % (its staggered halves lose their balance) -> the 5-tap tiles keep the round-5 form.
+    constexpr bool FASTADDR = !UP2 && KW == 3;
     constexpr int RSA = BMc * 2 + 64;
     constexpr int TA_BYTES = 32 * RSA;
     constexpr int XROWS = KW == 5 ? 64 : 48, XHALF = XROWS * 64, TB_BYTES = NH * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows; W = 4: 8 lines x 8 (6) rows
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     constexpr int REDB = NTt * 8 * 4;                            // bias partial sums
     // 8-wave tiles sit at the 256-register limit: their bias column sums live in an LDS table behind the stage buffers (ds_add_f32 on
     // the thread's own slots, same order of additions as the register form) instead of eight registers held through the main loop
-    constexpr bool BLDS = NWAVE == 8 && FASTADDR;
+    constexpr bool BLDS = false;      // (measured: ds_add_f32 on a [8][threads] table costs 40-170 % on launches WITH a bias gradient -- registers it is)
     constexpr int LDSB0 = 2 * STAGE > EPIB ? (2 * STAGE > REDB ? 2 * STAGE : REDB) : (EPIB > REDB ? EPIB : REDB);
     constexpr int LDSB = LDSB0 + (BLDS ? REDB : 0);
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
@@ -721,6 +721,9 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
 #endif
 template <int KW, int AW, int BW, int WCO, int WCI, bool RELU, int DEPTH = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
+    // bias column sums: eight registers, except on the pinned tile (no register left): an LDS table updated with ds_add_f32 -- SLOW
+    // (a launch with a bias gradient ran 2x longer), so the planner never sends a bias gradient to that tile; the path only keeps it correct
+    constexpr bool BLDS = KW == 3 && AW * BW * KW > 16;        // (5 taps: 20 tiles, four of them in VGPRs -- registers to spare)
     static_assert(WCO * WCI == 4, "four waves, one per SIMD");
     constexpr int NTt = 256, BMc = WCO * AW * 32, NHB = WCI * BW, BNc = NHB * 32;
     constexpr int RSA = BMc * 2 + 64;
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     constexpr int SUB = TA_BYTES + TB_BYTES;
     constexpr int EPIB = 4 * 32 * 32 * 4, REDB = NTt * 8 * 4;
     constexpr int LDSB0 = 3 * SUB > EPIB ? (3 * SUB > REDB ? 3 * SUB : REDB) : (EPIB > REDB ? EPIB : REDB);
-    constexpr int LDSB = LDSB0 + REDB;                           // + the bias column sums [8][256] (LDS table: no registers held through the loop)
+    constexpr int LDSB = LDSB0 + (BLDS ? REDB : 0);              // + the bias column sums [8][256] (pinned tile)
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WCI, wn = wave % WCI;
@@ -853,8 +856,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     const bool do_bias = p.dbias != nullptr && dtl == 0 && (spread || (dyl == 0 && tci == 0));
     const int nshare = spread ? KW * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
     int bphase = 0;
-    float* btab = reinterpret_cast<float*>(&smem[LDSB0]) + tid;       // [8][256] floats, slot k of this thread at btab[k * NTt]
-    if (do_bias) {
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float* btab = reinterpret_cast<float*>(&smem[BLDS ? LDSB0 : 0]) + tid;       // BLDS: [8][256] floats, slot k of this thread at btab[k * NTt]
+    if (BLDS && do_bias) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) btab[k * NTt] = 0.f;
     }
@@ -867,7 +871,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
                                     __uint_as_float(R[op].z << 16), __uint_as_float(R[op].z & 0xffff0000u),
                                     __uint_as_float(R[op].w << 16), __uint_as_float(R[op].w & 0xffff0000u)};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(btab + k * NTt, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int k = 0; k < 8; ++k) {
+                    if constexpr (BLDS) __hip_atomic_fetch_add(btab + k * NTt, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else bs[k] += v[k];
+                }
             }
         } else {
             const int i = op - NPA;
@@ -898,7 +905,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     constexpr int UB = NU - 2;                                   // the sub-step's barrier sits in front of unit UB (two units of fragments read ahead)
     // A fragments: ONE register set.  fa[a] is re-read for the next k half in the slot right after its last MFMA of this one
     // (AW - 1 slots, ~100 cycles, before its first use there) -- a second set would cost the 16 registers the second staging set needs.
-    bf16x8 fa[AW], fb[3];
+    // B fragments: a ring read two units ahead; its length must divide the units of a sub-step (the ring index runs on across
+    // sub-steps): 3 for 12 / 6 units (3 taps), 5 for 10 units (5 taps, one in-channel block per wave)
+    constexpr int RING = NU % 3 == 0 ? 3 : 5;
+    static_assert(NU % RING == 0, "B fragment ring");
+    bf16x8 fa[AW], fb[RING];
     auto ldA = [&](const char* st, int kb, int a) __attribute__((always_inline)) {
         const char* pz = st + aoff + kb * 16 * RSA + a * 64;
         fa[a] = tr2(pz, pz + 4 * RSA);
@@ -958,8 +969,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
                     if (!(DVD_EXP_ROW4 & 4)) __builtin_amdgcn_s_barrier();
                 }
                 if constexpr (a == 0) {                                  // B fragment two units ahead (the last two reach into the next sub-step)
-                    if (u + 2 < NU) ldB(rd, u + 2, (u + 2) % 3);
-                    else ldB(nx, u + 2 - NU, (u + 2) % 3);
+                    if (u + 2 < NU) ldB(rd, u + 2, (u + 2) % RING);
+                    else ldB(nx, u + 2 - NU, (u + 2) % RING);
                 }
                 if constexpr (a == 1) {
 #pragma unroll
@@ -979,8 +990,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
                 // geometry of the next sub-step's loads, a piece per slot (the slots behind the barrier carry little else)
                 if constexpr (u == UB - 1 && a == AW - 1) geo_part(gn, mk + 32 * (DEPTH + 2), 0);
                 if constexpr (u == UB && a >= 1) geo_part(gn, mk + 32 * (DEPTH + 2), a);
-                if constexpr (PIN) mfma_pinned<((a * BW + b) * KW + t >= 16)>(acc[a][b][t], fa[a], fb[u % 3]);
-                else acc[a][b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[u % 3], acc[a][b][t], 0, 0, 0);
+                if constexpr (PIN) mfma_pinned<((a * BW + b) * KW + t >= 16)>(acc[a][b][t], fa[a], fb[u % RING]);
+                else acc[a][b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[u % RING], acc[a][b][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
             gl = gn;
@@ -992,6 +1003,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
         __syncthreads();
     }
     if (do_bias) {
+        if constexpr (!BLDS) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) btab[k * NTt] = bs[k];
+        }
         __syncthreads();
         if (tid < CPRA) {
             for (int k = 0; k < 8; ++k) {
@@ -1192,18 +1207,23 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         // the two 4-wave workgroups per CU of the 64-channel form stay 3 % ahead
         const bool ci128 = (d->Cin_real + 127) / 128 * 128 == (d->Cin_real + 63) / 64 * 64;      // 128-channel input tiles pad no further
         if (ta == 2 && d->kw == 5 && !d->up2 && ci128) tb = 2;
-#ifndef DVD_WG_ROW4                    // 0 = 8-wave tiles only, 1 = the 128 x 128 one-wave-per-SIMD tile only, 2 = + the pinned 256 x 128 tile (default)
-#define DVD_WG_ROW4 2
+#ifndef DVD_WG_ROW4                    // 0 = 8-wave tiles only, 1 = the 128 x 128 one-wave-per-SIMD 3-tap tile only, 2 = + the pinned 256 x 128 tile, 3 = + 5 taps
+#define DVD_WG_ROW4 3
 #endif
 #ifndef DVD_ROW4_DEPTH                 // staging depth of the 128 x 128 one-wave-per-SIMD tile (experiment knob)
 #define DVD_ROW4_DEPTH 2
 #endif
-        // 3 taps (round 6): one wave per SIMD with the whole register file -- 256 x 128 (or 128 x 128) channel tiles, mode 2
-        // (needs a round of workgroups with >= 4096 rows each: 256 x 256 channels on 48 k rows ran 172 us against 101 on the 8-wave tile)
-        if (DVD_WG_ROW4 && d->kw == 3 && !d->up2 && ci128 && ta >= 2) {
-            const int t4 = DVD_WG_ROW4 == 1 ? 2 : ta;
-            const long long wgs = (long long)((d->Cout + t4 * 64 - 1) / (t4 * 64)) * ((d->Cin_real + 127) / 128) * d->kt * d->kh * (M / 4096);
-            if (wgs >= 224) { mode = 2; tb = 2; ta = t4; }
+        // round 6: one wave per SIMD with the whole register file (conv_wgrad_row4_kernel), mode 2.
+        //   3 taps: 256 x 128 channels (pinned, 24 tiles; not with a bias gradient) or 128 x 128
+        //   5 taps: 256 x 64 or 128 x 128 (20 tiles)
+        // Needs a round of workgroups with >= 4096 rows each (256 x 256 channels on 48 k rows ran 172 us against 101 on the 8-wave tile);
+        // a caller-forced split (msplit > 0: tests) takes the tile whatever the size.
+        if (DVD_WG_ROW4 && !d->up2 && ta >= 2 && (d->kw == 3 ? ci128 : (DVD_WG_ROW4 >= 3 && (ta == 4 || ci128)))) {
+            int t4 = ta, b4 = 2;
+            if (d->kw == 3) { if (DVD_WG_ROW4 == 1 || d->dbias) t4 = 2; }
+            else if (ta == 4) b4 = 1;
+            const long long wgs = (long long)((d->Cout + t4 * 64 - 1) / (t4 * 64)) * ((d->Cin_real + b4 * 64 - 1) / (b4 * 64)) * d->kt * d->kh * (M / 4096);
+            if (wgs >= 224 || d->msplit > 0) { mode = 2; tb = b4; ta = t4; }
         }
     }
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
@@ -1303,13 +1323,12 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
         do { if (d->relu_in) conv_wgrad_row_kernel<2, KW_, true, false, 4><<<grid, 512, 0, st>>>(p);    \
              else conv_wgrad_row_kernel<2, KW_, false, false, 4><<<grid, 512, 0, st>>>(p); } while (0)
         if (mode == 2) {
-#if DVD_WG_ROW4 == 2
-            if (ta == 4) { if (d->relu_in) conv_wgrad_row4_kernel<3, 4, 2, 2, 2, true><<<grid, 256, 0, st>>>(p);
-                           else conv_wgrad_row4_kernel<3, 4, 2, 2, 2, false><<<grid, 256, 0, st>>>(p); }
-            else
-#endif
-                         { if (d->relu_in) conv_wgrad_row4_kernel<3, 4, 1, 1, 4, true, DVD_ROW4_DEPTH><<<grid, 256, 0, st>>>(p);
-                           else conv_wgrad_row4_kernel<3, 4, 1, 1, 4, false, DVD_ROW4_DEPTH><<<grid, 256, 0, st>>>(p); }
+#define LAUNCH_ROW4(KW_, AW_, BW_, WCO_, WCI_, DEPTH_)                                                                        \
+            do { if (d->relu_in) conv_wgrad_row4_kernel<KW_, AW_, BW_, WCO_, WCI_, true, DEPTH_><<<grid, 256, 0, st>>>(p);       \
+                 else conv_wgrad_row4_kernel<KW_, AW_, BW_, WCO_, WCI_, false, DEPTH_><<<grid, 256, 0, st>>>(p); } while (0)
+            if (d->kw == 3) { if (ta == 4) LAUNCH_ROW4(3, 4, 2, 2, 2, 2); else LAUNCH_ROW4(3, 4, 1, 1, 4, DVD_ROW4_DEPTH); }
+            else            { if (ta == 4) LAUNCH_ROW4(5, 4, 1, 2, 2, 2); else LAUNCH_ROW4(5, 4, 1, 1, 4, 2); }
+#undef LAUNCH_ROW4
         } else
         if (d->up2) { if (ta == 4) LAUNCH_ROW_UP(4); else if (ta == 2) LAUNCH_ROW_UP(2); else LAUNCH_ROW_UP(1); }
         else if (tb == 2) { if (d->kw == 5) LAUNCH_ROW_W(5); else LAUNCH_ROW_W(3); }

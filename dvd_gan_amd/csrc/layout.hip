@@ -120,7 +120,7 @@ extern "C" int dvd_clip_to_tensor(const unsigned char* src, const unsigned char*
     return launch_status();
 }
 
-extern "C" int dvd_abi_version(void) { return 11; }
+extern "C" int dvd_abi_version(void) { return 12; }
 extern "C" int dvd_struct_size(int which) {
     switch (which) {
         case DVD_STRUCT_CONV: return (int)sizeof(dvd_conv_desc);

@@ -577,6 +577,8 @@ extern "C" int dvd_sepattn_forward(int dtype, const void* qkv, int ldq, int Cq, 
     const long long per = (long long)Cq * g.N * 3 / 2 + (long long)C * g.N / 2;
     const int PL = g.D1 * g.D2, NC = 2 * Cq + C;
     if ((size_t)2 * 8 * (NC + 1) * sizeof(float) > 64 * 1024) return DVD_E_SHAPE;
+    // (every validation before the first launch) the partial score sums live in `y` until sep_out_kernel writes it
+    if ((long long)kSepSplit * g.A * (g.A / 2) * 4 > g.N * ldx * (dtype == DVD_BF16 ? 2 : 4)) return DVD_E_SHAPE;       // (never: N >= 8 A)
     // positions per tile: as many as 64 KB of LDS hold (two attended coordinates x TP rows of NC + 1 floats)
 #define SEP_TILED(KERNEL, ...)                                                                                                         \
     do {                                                                                                                               \
@@ -592,7 +594,6 @@ extern "C" int dvd_sepattn_forward(int dtype, const void* qkv, int ldq, int Cq, 
     else SEP_TILED(sep_gather_kernel, g, (const T*)qkv, ldq, koff, voff, Qf, Kp, Vp, ksel, vsel);
     // the partial score sums live in `y` until sep_out_kernel writes it (B * 8 * A * A/2 floats; y holds B * N * ldx elements)
     float* part = reinterpret_cast<float*>(y);
-    if ((long long)kSepSplit * g.A * (g.A / 2) * 4 > g.N * ldx * (dtype == DVD_BF16 ? 2 : 4)) return DVD_E_SHAPE;       // (never: N >= 8 A)
     sep_prod_kernel<true><<<dim3(kSepSplit, (unsigned)B), 1024, 0, S_>>>(Qf, Kp, part, g.A, g.A / 2, (long long)Cq * g.D1 * g.D2);
     sep_softmax_kernel<<<dim3(g.A, (unsigned)B), 64, 0, S_>>>(part, att, g.A, g.A / 2);
     if (ldx != C &&      // padded channel columns of y must read zero afterwards (sep_out_kernel writes the real ones only)

@@ -180,6 +180,9 @@ class SwapFrameOrder(Function):
 
 
 # ------------------------------------------------------------------ convolution
+POOL2_FUSED = _os.environ.get("DVD_POOL2_FUSED", "1") != "0"      # A/B aid: 0 = up2 backward-data as conv + dvd_pool (round-5 form)
+
+
 class ConvSpec:
     """Static description + per-forward state of one convolution call."""
 
@@ -233,17 +236,23 @@ class Conv(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if spec.up2:
-                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, wq=lambda: pk.fragment_major("wd"))
-                dx = K.pool(dx, 1, scale=1.0, mask=x if spec.relu_in else None)      # transpose of nearest x2 (+ ReLU mask)
+                # transpose of nearest x2 (+ ReLU mask): 2 x 2 sums in the conv's epilogue (round 6), else a pool pass over the
+                # full-size result (exact mode on the tap-by-tap kernels, frames below 16 pixels)
+                dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, wq=lambda: pk.fragment_major("wd"), pool2=True,
+                                    mask=x if spec.relu_in else None) if POOL2_FUSED else None
+                if dx is None:
+                    dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, wq=lambda: pk.fragment_major("wd"))
+                    dx = K.pool(dx, 1, scale=1.0, mask=x if spec.relu_in else None)
             else:
                 partner = None
                 if ctx.slot is not None:                  # the other branch's gradient of the same x: summed in the epilogue
                     partner, ctx.slot.dx = ctx.slot.dx, None
                     assert not spec.relu_in
-                    if partner is None:
-                        raise RuntimeError("GradSlot: the main branch of this residual block has not left its input gradient -- its "
-                                           "backward node did not run before the shortcut's (graph pruned or re-entered?); the sum "
-                                           "d/dx would silently lose a term")
+                    # partner None: the main branch's backward node did not run in this pass.  The token the main branch takes from
+                    # this conv orders its node BEFORE this one whenever the engine runs it at all, so a missing partner means the
+                    # engine pruned the main branch -- torch.autograd.grad(loss, [block.conv_sc.weight]) needs no d/dx of the block
+                    # input, runs this node for its weight only and DISCARDS the dx computed here (needs_input_grad[0] is fixed at
+                    # forward time).  Nothing is lost: dx is the shortcut's own term (tests/test_gpu_modules.py, pruned-graph case).
                 dx = K.conv_forward(dy, pk.wd, spec.ksize, pk.cip, mask=x if spec.relu_in else None, res=partner,
                                     wq=lambda: pk.fragment_major("wd"))
         wp, bp = ctx.params

@@ -164,7 +164,7 @@ class Generator(nn.Module):
         try:
             return self._forward(x, class_id, hidden)
         finally:
-            for m in counted:
+            for m in counted:                     # (only modules that were counting are switched back on)
                 m.count_batches = True
             clear_spectral_norm(sn)
 
@@ -173,8 +173,11 @@ class Generator(nn.Module):
         multi-tensor launch.  The counters stay the modules' own buffers (nothing is re-homed: shadow copies, EMA code and
         `.to()` keep seeing the tensors they hold); the layers' own increment is switched off only for the duration of this
         forward, so a ConditionalNorm / GResBlock driven on its own afterwards counts for itself again."""
-        mods = [m for m in self.modules() if isinstance(m, ConditionalNorm)]
-        torch._foreach_add_([m.bn.num_batches_tracked for m in mods], 1)
+        # like BatchNorm2d (Normalization.py:72) the counter follows each module's OWN training flag; a layer whose caller switched
+        # its counting off (count_batches = False) stays untouched and keeps that setting
+        mods = [m for m in self.modules() if isinstance(m, ConditionalNorm) and m.training and m.count_batches]
+        if mods:
+            torch._foreach_add_([m.bn.num_batches_tracked for m in mods], 1)
         return mods
 
     def _forward(self, x, class_id, hidden=None):

@@ -152,9 +152,12 @@ def _thin_out_image(wpack):
 
 
 def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L.ACT_NONE, up2=False,
-                 relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None, res_up2=False, wq=None):
+                 relu_in=False, out=None, out_f32=False, nsplit=1, ws=None, slabs=False, cout_pad=None, res_up2=False, wq=None,
+                 pool2=False):
     """Direct (nsplit=1) or split-K convolution.  `wpack`: [ntaps][cout][Cp] tensor.  Returns the
-    output tensor [F,(T,)H,W,cout_pad] (direct) or the fp32 slabs [nsplit, M, cout] (split-K)."""
+    output tensor [F,(T,)H,W,cout_pad] (direct) or the fp32 slabs [nsplit, M, cout] (split-K).
+    pool2: return the 2 x 2 SUMS of the result on the half-size grid [F, H/2, W/2, cout_pad] (`mask` lives there too), formed in the
+    kernel's epilogue -- or None when this request is not served that way (the caller then pools a full-size result)."""
     k = _ksize3(ksize)
     F_, T, H, W = _grid(x, ksize, up2)
     Cp = x.shape[-1]
@@ -178,6 +181,17 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
         d.wq_kind = want if wq is not None else 0
     d.wq = wq.data_ptr() if wq is not None else None
     d.out = d.ws = None
+    if pool2:
+        d.pool2 = 1
+        d.ldo = cout_pad or pad8(cout)
+        if x.dim() != 4 or nsplit > 1 or slabs or ws is not None or not L.lib().dvd_conv_pool2_ok(C.byref(d)):
+            return None
+        shape = (F_, H // 2, W // 2, d.ldo)
+        alloc = torch.zeros if d.ldo != cout else torch.empty
+        out = alloc(shape, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        d.out = out.data_ptr()
+        L.check(L.lib().dvd_conv_forward(C.byref(d), L.stream()))
+        return out
     nk = k[0] * k[1] * k[2] * ((Cp + (31 if x.dtype == torch.bfloat16 else 15)) // (32 if x.dtype == torch.bfloat16 else 16))
     nsplit = d.nsplit = max(1, min(nsplit, nk))
     if nsplit > 1 or slabs or ws is not None:

@@ -18,7 +18,8 @@ class ConvDesc(C.Structure):
                 ("nsplit", C.c_int), ("act", C.c_int), ("out_f32", C.c_int), ("ldres", C.c_int),
                 ("ldmask", C.c_int), ("res_up2", C.c_int),
                 ("inp", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
-                ("mask", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("wq", C.c_void_p), ("wq_kind", C.c_int)]
+                ("mask", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("wq", C.c_void_p), ("wq_kind", C.c_int),
+                ("pool2", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -61,7 +62,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 BN_NREP = 16            # DVD_BN_NREP of include/dvdgan_hip.h
 SN_SCRATCH = 512        # DVD_SN_SCRATCH
 

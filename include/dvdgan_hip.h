@@ -105,8 +105,16 @@ typedef struct {
                                   straight from L2 into registers instead of staging it in LDS       */
     int wq_kind;               /* what `wq` holds: 0 / 1 = the fragment-major image, 2 = dvd_conv_thin_image, 3 = dvd_conv_thin_out_image
                                   (the value dvd_conv_wants_fragment_major returned for this request) */
+    int pool2;                 /* ABI 12: != 0 -> `out` (and `mask`) live on the HALF-size grid [frames][H/2][W/2][ldo] and receive the
+                                  2 x 2 SUMS of the convolution result -- the transpose of a nearest x2 upsample, i.e. the input gradient
+                                  of a convolution that read an upsampled input (GResBlock.py:57-58) -- formed on the fp32 accumulators
+                                  in the epilogue instead of by a dvd_pool pass over a full-size intermediate.  Served by the
+                                  halo-staged kernels only: ask dvd_conv_pool2_ok() first.                                   */
 } dvd_conv_desc;
 int dvd_conv_forward(const dvd_conv_desc* d, void* stream);
+/* 1 when dvd_conv_forward serves `d` with d->pool2 set (square 3 / 5 taps, power-of-two frames >= 16 pixels, one K slice,
+ * no residual / activation / ConvGRU epilogue), else 0 (the caller runs the plain request and dvd_pool). */
+int dvd_conv_pool2_ok(const dvd_conv_desc* d);
 /* Fragment-major weight image: [tap][32-channel chunk][32-column block, padded to whole 128-column tiles][k-half pair][lane]
  * [8 channels] -- 1 KiB per MFMA B fragment, fetched by one coalesced 16-byte load per lane.  `w`: a forward or backward-data
  * pack of dvd_pack_conv_weight ([ntaps][Cout][C], bf16, C % 8 == 0).  Re-run after every re-pack (spectral norm: every forward). */
@@ -411,7 +419,9 @@ int dvd_maxpool3d_backward(int dtype, const void* x, const void* dy, void* dx, l
  * SeparableAttnCell (Module/Attention.py:24-111; the T / W / H cells of SeparableAttn, :8-21): attention along ONE axis of a
  * [B, T, W, H, C] channels-last clip, built -- like the reference -- from raw reshapes of the contiguous NCDHW projections
  * (see csrc/sepattn.hip).  q | k | v are columns [0,Cq) | [koff,koff+Cq) | [voff,voff+C) of `qkv` (one fused 1x1 conv);
- * axis: 0 = T, 1 = W, 2 = H; T, W, H even; attended size / 2 <= 64.  Work arrays are per call, sized by the caller:
+ * axis: 0 = T, 1 = W, 2 = H; T, W, H even; attended size A <= 64 (DVD_E_SHAPE otherwise: the score / gradient product tiles are
+ * 64 x 32; n_frames > 64 or a 128-pixel attended axis is not served).  Every shape / scratch check runs BEFORE the first launch.
+ * Work arrays are per call, sized by the caller:
  *   Qf [B][Cq*N], Kp [B][Cq*N/2], Vp [B][C*N/2] fp32, ksel / vsel bytes of the same counts (max-pool winners),
  *   att [B][A][A/2]   (N = T*W*H; dvd_sepattn_work_floats = floats of Qf + Kp + Vp + att per clip)
  * backward additionally: dO [B][C*N], dS like att, dQf / dKp / dVp like Qf / Kp / Vp; writes the q | k | v columns of dqkv

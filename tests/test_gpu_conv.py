@@ -154,6 +154,15 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
         dx_nc = dx_nc * (xq > 0)
     assert rel(dx_nc, xq_.grad) < 3e-6
     assert rel(dx_nc, xr.grad) < (3e-6 if exact else 6e-3)
+    if up2:    # the same 2 x 2 sums (+ ReLU mask) formed in the conv's epilogue (round 6: dvd_conv_desc.pool2) where a halo kernel serves it
+        fused = K.conv_forward(gyc, pk.wd, ks, pk.cip, out_f32=True, pool2=True, mask=xc if relu_in else None,
+                               wq=lambda: pk.fragment_major("wd"))
+        assert (fused is not None) == (len(sp) == 2 and min(sp) >= 8 and all(v & (v - 1) == 0 for v in sp)), sp
+        if fused is not None:
+            assert fused.shape[1:3] == (sp[0], sp[1])
+            assert rel(K.from_cl(fused, Cin).cpu(), xq_.grad) < 3e-6
+            fused_b = K.conv_forward(gyc, pk.wd, ks, pk.cip, pool2=True, mask=xc if relu_in else None)      # storage dtype, weights through LDS
+            assert rel(K.from_cl(fused_b, Cin).cpu().float(), xq_.grad) < (3e-6 if exact else 4e-3)
 
     # backward-weight (fp32 atomics into the reference layout)
     dw = torch.zeros(Cout, Cin, *ks, device=dev)
@@ -168,6 +177,16 @@ def test_conv_forward_dgrad_wgrad(case, dtype):
     K.conv_wgrad(xc, gyc, dw2, ks, Cout, Cin, up2=up2, relu_in=relu_in, msplit=1)
     # one slice = one fp32 accumulator chain over all M rows: rounding grows with the chain length (131072 rows: 6.5e-6)
     assert rel(dw2.cpu(), wq_.grad) < 1e-5
+    # a caller-forced split also takes the one-wave-per-SIMD tiles (round 6) on shapes the planner would leave to the 8-wave tiles
+    # for lack of rows: two slices through the workspace, with and without the bias column sums
+    if int(torch.tensor(sp).prod()) * F_ >= 64:
+        dw3, db3 = torch.zeros_like(dw), torch.zeros(Cout, device=dev)
+        K.conv_wgrad(xc, gyc, dw3, ks, Cout, Cin, up2=up2, relu_in=relu_in, msplit=2, dbias=db3)
+        assert rel(dw3.cpu(), wq_.grad) < 1e-5
+        assert rel(db3.cpu(), gyq.transpose(0, 1).reshape(Cout, -1).sum(1)) < 5e-6
+        dw4 = torch.zeros_like(dw)
+        K.conv_wgrad(xc, gyc, dw4, ks, Cout, Cin, up2=up2, relu_in=relu_in, msplit=2)
+        assert rel(dw4.cpu(), wq_.grad) < 1e-5
 
 
 @pytest.mark.parametrize("case", [(5, (64, 64), (3, 3), True, 1, False), (3, (6, 32, 32), (3, 3, 3), False, 0, False),

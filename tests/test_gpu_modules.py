@@ -160,6 +160,25 @@ def test_gresblock_partial_autograd_leaves_no_stale_gradient(golden):
     assert torch.equal(a, b)
 
 
+def test_gresblock_gradient_of_the_shortcut_weight_alone(golden):
+    """The other pruned graph: torch.autograd.grad(loss, [conv_sc weight]) runs the shortcut conv's backward node but never
+    the main branch's conditional batch norm, so functional.GradSlot has no partner gradient.  The shortcut's own weight gradient
+    must come out (it used to raise) and equal the one a full backward leaves; a full backward afterwards is undisturbed."""
+    from dvd_gan_amd.gen_net import GResBlock
+    g = sub(golden("f3_gresblock"), "up1")
+    samp = torch.arange(6, dtype=torch.int32, device=DEV)
+    blk = load(GResBlock(8, 8, 12, 1), sub(g, "sd0")).train()
+    x = t(g["in.x"], True)
+    y = ncl(blk.run(cl(x, torch.float32), t(g["in.cond"]), samp), 8)
+    w = blk.conv_sc.module.weight_bar
+    gw, = torch.autograd.grad(y, [w], grad_outputs=t(g["in.gy"]), retain_graph=True)
+    for p in blk.parameters():
+        p.grad = None
+    y.backward(t(g["in.gy"]))
+    assert rel(gw, w.grad.cpu()) < 1e-6
+    assert rel(x.grad, g["grad.x"]) < 2e-4
+
+
 # ------------------------------------------------------------------ F5
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("tag,C", [("n16", 16), ("n64", 8)])

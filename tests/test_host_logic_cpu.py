@@ -1,6 +1,6 @@
-import pytest
 """Host-side logic that needs no GPU: the learning-rate schedules of trainer.py:142-176 against torch's own
 schedulers and frame sampling against utils.py:60-63 semantics."""
+import pytest
 import torch
 
 
