@@ -719,7 +719,7 @@ int stack_forward(const dvd_gru_stack_desc* s, void* stream, bool dry, long long
 }
 
 int stack_backward(const dvd_gru_stack_desc* s, void* stream, bool dry, long long& ws_need) {
-    const int L = s->n_layers, T = s->layer[0].T, kind = stack_kind(s);
+    const int L = s->n_layers, T = s->layer[0].T, kind_ = stack_kind(s);
     const long long M = (long long)s->layer[0].B * s->layer[0].H * s->layer[0].W;
     const size_t esz = 2;
     using T_ = bf16_t;
@@ -738,6 +738,10 @@ int stack_backward(const dvd_gru_stack_desc* s, void* stream, bool dry, long lon
         GruEpi epi[kMaxMember];
         for (int phase = 0; phase < 2; ++phase) {                 // 0 = A group, 1 = B group
             int n = 0;
+#ifndef DVD_A_GROUP_KIND                  // experiment: 1 = the A group of the >= 16-pixel stages on 128-row tiles (three workgroups per CU)
+#define DVD_A_GROUP_KIND 0
+#endif
+            const int kind = (phase == 0 && kind_ == 0 && DVD_A_GROUP_KIND) ? 1 : kind_;
             for (int l = L - 1; l >= 0; --l) {
                 const dvd_gru_desc& d = s->layer[l];
                 const int t = T - 1 - (k - 2 * (L - 1 - l)), h = d.hidden;

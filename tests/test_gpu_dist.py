@@ -70,9 +70,19 @@ def _run(world, tmp, mode="replica", backend="gloo"):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if backend == "gloo":
             env.update(DVD_SHARE_GPU0="1", DVD_DIST_BACKEND="gloo")
-        procs.append(subprocess.Popen([sys.executable, script, ROOT, os.path.join(tmp, "out"), mode], env=env))
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+        log = open(os.path.join(tmp, f"worker.{mode}.{world}.{r}.log"), "w")
+        procs.append(subprocess.Popen([sys.executable, script, ROOT, os.path.join(tmp, "out"), mode], env=env, stdout=log, stderr=log))
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    except BaseException:
+        for p in procs:                                    # a stuck rank must not outlive the test (and hold the GPU / the port)
+            if p.poll() is None:
+                p.kill()
+        for r in range(world):
+            print(f"---- rank {r} of {world} ({mode}, {backend})")
+            print(open(os.path.join(tmp, f"worker.{mode}.{world}.{r}.log")).read()[-3000:])
+        raise
     return [torch.load(os.path.join(tmp, f"out.{mode}.{world}.{r}")) for r in range(world)]
 
 
