@@ -246,7 +246,8 @@ def main():
                       8: "conv_halo_gbs_kernel<bf16, 128x128 tile, 4x4 / 8x8 frames>", 9: "conv_thin_in_kernel<bf16, 3 -> 64 channels>",
                       10: "conv_group_gb_kernel<bf16, 256x128 tiles, grouped ConvGRU wavefront launches>",
                       11: "conv_group_gbs_kernel<bf16, grouped ConvGRU wavefront launches on 4x4 / 8x8 frames>"},
-                  1: {1: "conv_wgrad_row_kernel", 2: "conv_wgrad_kernel", 3: "wgrad_thin_kernel"}}
+                  1: {1: "conv_wgrad_row_kernel<8-wave filter-row tiles>", 2: "conv_wgrad_kernel", 3: "wgrad_thin_kernel",
+                      4: "conv_wgrad_row4_kernel<one wave per SIMD: 3 taps 256x128 / 128x128, 5 taps 256x64 / 128x128>"}}
         for kind, name in ((0, "conv_igemm"), (1, "conv_wgrad")):
             NV = 12
             nn, tms, fl = (C.c_longlong * NV)(), (C.c_double * NV)(), (C.c_double * NV)()

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
     // 3 taps +1...4 % (8-wave tiles), +11 % (64-channel tile); 5 taps on the 128 x 128 tile +1.5 % but two spilled registers;
     // 5 taps on the 256 x 64 tile -4.5 % (its staggered halves lose their balance) -> the 5-tap tiles keep the round-5 form.
     constexpr bool FASTADDR = !UP2 && KW == 3;
+    constexpr bool UPFAST = UP2 && KW == 3;                       // the same for the x2-upsampled input of one-segment steps (W >= 32), chosen at run time
     constexpr int RSA = BMc * 2 + 64;
     constexpr int TA_BYTES = 32 * RSA;
     constexpr int XROWS = KW == 5 ? 64 : 48, XHALF = XROWS * 64, TB_BYTES = NH * XHALF;   // W = 8, 5 taps: 4 lines x 12 rows; W = 4: 8 lines x 8 (6) rows
@@ -429,7 +430,12 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
             xa[i] = wide ? xxa : xya;
             if (!wide) xcv[i] = xcv[i] && (unsigned)xxa < (unsigned)p.W;
         }
+        if constexpr (UPFAST) {           // x2-upsampled input, one line segment per step (W >= 32): input row = uniform + (xj - cpad)
+            xa[i] = xj[i] - cpad;
+            xld[i] = (unsigned)xa[i] * ldx2 + xcb[i];
+        }
     }
+    const bool upfast = UPFAST && p.W >= 32;
     const unsigned yld = (unsigned)rra * ldy2 + (unsigned)cy * 2;
     const int dt_rows = p.kt > 1 ? dtl << (p.logW + p.logH) : 0;
     u32x4 ra[NS][NPA], rb[NS][NXL];
@@ -455,6 +461,26 @@ __global__ __launch_bounds__(WM * NH * 64) void conv_wgrad_row_kernel(WgK p) {
 #pragma unroll
             for (int i = 0; i < NXL; ++i) {
                 const bool ok = xcv[i] && tok && (unsigned)(sval + xa[i]) < slim;
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xld[i] + xoff : 0xffffffffu, 0, 0);
+            }
+            return;
+        }
+        if (UPFAST && upfast) {
+            // one 32-pixel segment of an OUTPUT line: its input line (yy >> 1) is wave-uniform, the input column is (x0 >> 1) - cpad + xj
+            const bool ytok = mk < m_end;
+            const int x0 = mk & (p.W - 1), y = (mk >> p.logW) & (p.H - 1), yy = y + dyl;
+            const bool tok = ytok && (unsigned)yy < (unsigned)p.H;
+            const int xs = x0 >> 1;
+            const unsigned yoff = (unsigned)(mk - m_begin) * ldy2;
+            const unsigned xoff = (unsigned)((mk >> (p.logW + p.logH)) * (p.Hin * p.Win) + (yy >> 1) * p.Win + xs - xbase_row) * ldx2;
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                const unsigned off = (cyv && ytok) ? yld + yoff + (unsigned)(i * RPPA) * ldy2 : 0xffffffffu;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) {
+                const bool ok = xcv[i] && tok && (unsigned)(xs + xa[i]) < (unsigned)p.Win;
                 rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xld[i] + xoff : 0xffffffffu, 0, 0);
             }
             return;
@@ -1272,7 +1298,10 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         //  384 498.1 / 498.1, 512 495.6 / 495.7, 768 497.7 / 498.5, 1024 498.4 / 497.3, 1536 500.4 / 500.3, 3072 501.3 ms, one box)
         constexpr long long tgt_row = 512;
         const long long base = (long long)p.tiles_co * p.tiles_ci * (mode >= 1 ? d->kt * d->kh : ntaps);
-        msplit = ((mode >= 1 ? tgt_row : tgt) + base - 1) / base;
+#ifndef DVD_WGR4_TGT                   // workgroups per launch of the one-wave-per-SIMD tiles (one per CU at a time: 256 = one round).  Step,
+#define DVD_WGR4_TGT 256               // interleaved on one box: 256 451.3 / 451.8 ms, 512 452.1 / 452.3, 768 454.5 / 454.2 (half the slice workspace per halving)
+#endif
+        msplit = ((mode == 2 ? (long long)DVD_WGR4_TGT : mode == 1 ? tgt_row : tgt) + base - 1) / base;
         long long cap = M / minrows > 0 ? M / minrows : 1;
         if (ntaps == 1 && cap * base < 256) {
             // short 1 x 1 layers (shortcut and attention projections on <= 16-pixel maps): 16 workgroups of 4096 rows each took
@@ -1335,7 +1364,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
-    prof.r.variant = mode >= 1 ? 1 : 2;
+    prof.r.variant = mode == 2 ? 4 : mode == 1 ? 1 : 2;        // (dvd_prof_report_variants: 1 = 8-wave filter-row tiles, 2 = one tap, 3 = thin ends, 4 = one wave per SIMD)
     if (mode >= 1) {
 #define LAUNCH_ROW(WM_, KW_)                                                                        \
         do { if (d->relu_in) conv_wgrad_row_kernel<WM_, KW_, true><<<grid, WM_ * 128, 0, st>>>(p);      \
