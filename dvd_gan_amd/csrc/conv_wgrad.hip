@@ -1298,10 +1298,11 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         //  384 498.1 / 498.1, 512 495.6 / 495.7, 768 497.7 / 498.5, 1024 498.4 / 497.3, 1536 500.4 / 500.3, 3072 501.3 ms, one box)
         constexpr long long tgt_row = 512;
         const long long base = (long long)p.tiles_co * p.tiles_ci * (mode >= 1 ? d->kt * d->kh : ntaps);
-#ifndef DVD_WGR4_TGT                   // workgroups per launch of the one-wave-per-SIMD tiles (one per CU at a time: 256 = one round).  Step,
-#define DVD_WGR4_TGT 256               // interleaved on one box: 256 451.3 / 451.8 ms, 512 452.1 / 452.3, 768 454.5 / 454.2 (half the slice workspace per halving)
-#endif
-        msplit = ((mode == 2 ? (long long)DVD_WGR4_TGT : mode == 1 ? tgt_row : tgt) + base - 1) / base;
+        // one-wave-per-SIMD tiles (one workgroup per CU at a time): ONE round of 256 workgroups -- step at C2, interleaved on one box:
+        // one round 451.3 / 451.8 ms, two 452.1 / 452.3, three 454.5 / 454.2 (half the slice workspace per halving) -- two rounds
+        // beyond 6 M rows (configs[3], 4x the rows per launch: one round 1802 ms, two 1739)
+        const long long tgt4 = M > (6ll << 20) ? 512 : 256;
+        msplit = ((mode == 2 ? tgt4 : mode == 1 ? tgt_row : tgt) + base - 1) / base;
         long long cap = M / minrows > 0 ? M / minrows : 1;
         if (ntaps == 1 && cap * base < 256) {
             // short 1 x 1 layers (shortcut and attention projections on <= 16-pixel maps): 16 workgroups of 4096 rows each took
@@ -1328,6 +1329,18 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     rows = (rows + 31) / 32 * 32;
     if (rows < 32) rows = 32;
     msplit = (M + rows - 1) / rows;
+    if (mode == 2 && d->msplit < 1) {
+        // the 32-bit offset cap can undo the whole-round rounding above (configs[3]: 3.1 M x 512 -> 512 behind a 1536-wide dy: 5 slices x 80
+        // workgroups = 1.56 rounds of one workgroup per CU): fill the last round
+        const long long base = (long long)p.tiles_co * p.tiles_ci * d->kt * d->kh, wg = base * msplit;
+        if (wg > 256 && wg % 256 > 0 && wg % 256 < 192) {
+            const long long ms2 = ((wg + 255) / 256 * 256) / base;
+            if (ms2 > msplit && M / ms2 >= 2048) {
+                rows = ((M + ms2 - 1) / ms2 + 31) / 32 * 32;
+                msplit = (M + rows - 1) / rows;
+            }
+        }
+    }
     p.rows_per_split = (int)rows;
     grid = dim3(p.tiles_co * p.tiles_ci * (mode >= 1 ? d->kt * d->kh : ntaps), 1, (unsigned)msplit);
     return DVD_OK;
