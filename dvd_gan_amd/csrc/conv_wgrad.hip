@@ -21,6 +21,7 @@ struct WgK {
     float* dbias;
     float* wsb;             // row kernel, workspace path: bias partial sums [slice][workgroup][BMc] behind the tile partials
     float* ws;                           // partial tiles [slice][x-block][BMc*BNc] when non-null
+    int fold, cout_f;                    // conv_wgrad_row4_kernel<FOLD>: x2-upsampled input folded onto the input grid (cout_f = the layer's Cout)
 };
 
 // D[co][ci] = sum over rows m of dy[m][co] * x[pos(m)+tap][ci].  The reduction index (rows) is the
@@ -745,7 +746,17 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
 #ifndef DVD_EXP_ROW4                  // timing-only experiment builds (wrong results): 1 = no global loads, 2 = no LDS stores, 4 = no barrier
 #define DVD_EXP_ROW4 0
 #endif
-template <int KW, int AW, int BW, int WCO, int WCI, bool RELU, int DEPTH = 2>
+// FOLD (round 6): the weight gradient of a 3 x 3 convolution over a nearest-x2 UPSAMPLED input (GResBlock.py:57-58), worked on the
+// INPUT grid.  Output pixel (2i + a, 2j + b) reads input pixel (i + ((a + ky) >> 1), j + ((b + kx) >> 1)) for tap (ky, kx) in -1..1,
+// so   dw[ky][kx] = sum over phases (a, b) of  G[a][sy][b][sx],  sy = (a + ky) >> 1, sx = (b + kx) >> 1,
+//      G[a][sy][b][sx][co][ci] = sum over input pixels q of  dy[2q + (a, b)][co] * x[q + (sy, sx)][ci]
+// -- an ordinary 3 x 3 weight gradient on the input grid whose "output channels" are the four phases of dy side by side
+// (co' = (2a + b) * Cout + co: rows of dy two apart, found by address arithmetic, nothing is re-laid-out), with only the filter rows
+// sy in {a - 1, a} of phase a: 2 rows x 3 taps x 4 Cout x M / 4 = 2 / 3 of the products of the direct form (the third tap of a row is
+// unused for either b: computed and dropped), on the one-wave-per-SIMD 128 x 128 tile instead of the 8-wave x2 tiles (0.43-0.9 PF/s;
+// the 64-channel one, 12.5 M x 128 -> 64 on 64 x 64 frames, took 4.3 ms of a step).  Partial tiles always go through the slice
+// workspace; wgrad_fold_reduce_kernel forms dw from them.  p.H / p.W / p.M are the INPUT grid's, p.Cout = p.Cy = 4 * cout_f.
+template <int KW, int AW, int BW, int WCO, int WCI, bool RELU, int DEPTH = 2, bool FOLD = false>
 __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     // bias column sums: eight registers, except on the pinned tile (no register left): an LDS table updated with ds_add_f32 -- SLOW
     // (a launch with a bias gradient ran 2x longer), so the planner never sends a bias gradient to that tile; the path only keeps it correct
@@ -775,8 +786,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     const int tco = rem / p.tiles_ci, tci = rem - tco * p.tiles_ci;
     const int co0 = tco * BMc, ci0 = tci * BNc;
     constexpr int pad = KW >> 1;
-    const int it = irow / KW, iy = irow - it * KW;
-    const int dyl = iy - pad, dtl = it - (p.kt >> 1);
+    static_assert(!FOLD || (KW == 3 && BMc == 128), "the folded form runs on the 3-tap 128-channel tile");
+    // FOLD: irow = 0 / 1 = filter row a - 1 / a of the tile's line phase a (a 128-channel tile lies inside one a: Cout is a multiple of 64)
+    const int it = FOLD ? 0 : irow / KW, iy = FOLD ? irow : irow - it * KW;
+    const int dyl = FOLD ? ((co0 / p.cout_f) >> 1) - 1 + irow : iy - pad, dtl = FOLD ? 0 : it - (p.kt >> 1);
     const int m_begin = bz * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
@@ -791,7 +804,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
                 for (int t = 0; t < KW; ++t) acc[a][b][t] = zacc;
     }
     const int xbase_row = max(0, m_begin - p.maxshift);
-    const size_t xbase_b = (size_t)xbase_row * p.ldx * 2, ybase_b = (size_t)m_begin * p.ldy * 2;
+    // FOLD: rows of dy are on the output grid: input pixel mk = (line L, column x0) -> output row 4 * mk - 2 * x0 (+ the phase's a * 2W + b)
+    const int ybase_row = FOLD ? 4 * m_begin - 2 * (p.W > 32 ? m_begin & (p.W - 1) : 0) : m_begin;
+    const size_t xbase_b = (size_t)xbase_row * p.ldx * 2, ybase_b = (size_t)ybase_row * p.ldy * 2;
     const size_t xleft = p.x_bytes - xbase_b, yleft = p.dy_bytes > ybase_b ? p.dy_bytes - ybase_b : 0;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.x + xbase_b), 0, xleft > 0xfffffffeull ? 0xfffffffeu : (unsigned)xleft, 0x00020000);
@@ -836,7 +851,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
         const int delta = (fo << (p.logW + p.logH)) + (xya << p.logW) + xxa;
         xld[i] = (unsigned)delta * ldx2 + (unsigned)cx * 2;      // (wraps for negative deltas; the sum with the uniform part is exact)
     }
-    const unsigned yld = (unsigned)rra * ldy2 + (unsigned)cy * 2;
+    unsigned yld = (unsigned)rra * ldy2 + (unsigned)cy * 2;
+    unsigned ystep = (unsigned)RPPA * ldy2;                      // from staging chunk op to op + 1 of dy (RPPA rows further on)
+    if constexpr (FOLD) {
+        // row r = rra + 16 * op of the sub-step = input pixel (line r >> logsegw, column r & (segw - 1)) of its segment(s); phase (a, b)
+        // of the thread's channel chunk: output row  2 * line * 2W + 2 * column + a * 2W + b  past the sub-step's first
+        static_assert(!FOLD || RPPA == 16, "16 rows per staging pass");
+        const int ph = cy / p.cout_f, c = cy - ph * p.cout_f, W2 = 2 * p.W;
+        yld = (unsigned)(((rra >> logsegw) * 2 + (ph >> 1)) * W2 + 2 * (rra & (segw - 1)) + (ph & 1)) * ldy2 + (unsigned)c * 2;
+        ystep = (unsigned)(segw == 32 ? 32 : (16 >> logsegw) * 2 * W2) * ldy2;
+    }
     const int dt_rows = p.kt > 1 ? dtl << (p.logW + p.logH) : 0;
     u32x4 R[DEPTH][NOPS];      // staging registers: set d holds the chunks of every DEPTH-th sub-step, loaded DEPTH sub-steps before they are stored
     struct Geo { int sval; unsigned xoff, yoff; bool tok, ytok; };
@@ -857,7 +881,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
         } else if (part == 2) {
             g.xoff = (unsigned)(mk + dt_rows - xbase_row) * ldx2;
         } else {
-            g.yoff = (unsigned)(mk - m_begin) * ldy2;
+            if constexpr (FOLD) g.yoff = (unsigned)(4 * mk - 2 * (wide ? mk & (p.W - 1) : 0) - ybase_row) * ldy2;
+            else g.yoff = (unsigned)(mk - m_begin) * ldy2;
         }
     };
     auto geo = [&](int mk) __attribute__((always_inline)) -> Geo {
@@ -868,7 +893,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     };
     auto load_op = [&](int op, const Geo& g, u32x4 (&R)[NOPS]) __attribute__((always_inline)) {
         if (op < NPA) {
-            const unsigned off = (cyv && g.ytok) ? yld + g.yoff + (unsigned)(op * RPPA) * ldy2 : 0xffffffffu;
+            const unsigned off = (cyv && g.ytok) ? yld + g.yoff + (unsigned)op * ystep : 0xffffffffu;
             R[op] = __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0);
         } else {
             const int i = op - NPA;
@@ -880,7 +905,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
     // bias gradient shares: as in conv_wgrad_row_kernel (sub-step n belongs to share n % nshare)
     const bool spread = p.ws != nullptr;
     const bool do_bias = p.dbias != nullptr && dtl == 0 && (spread || (dyl == 0 && tci == 0));
-    const int nshare = spread ? KW * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
+    const int nshare = spread ? (FOLD ? 2 : KW) * p.tiles_ci : 1, myshare = spread ? iy * p.tiles_ci + tci : 0;
     int bphase = 0;
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float* btab = reinterpret_cast<float*>(&smem[BLDS ? LDSB0 : 0]) + tid;       // BLDS: [8][256] floats, slot k of this thread at btab[k * NTt]
@@ -1219,11 +1244,72 @@ __global__ void wgrad_reduce_kernel(WgRedK p) {
         if (ci + j < p.Cin_real) d[j * p.s_ci] = p.overwrite ? a[j] : d[j * p.s_ci] + a[j];
 }
 
+// Reduction of the folded form (conv_wgrad_row4_kernel<.., FOLD>): dw[co][ci][ky][kx] (+)= sum over the four phases (a, b), in that
+// order, of the slice sums of G[a][sy][b][sx] -- tile (filter row irow = sy - a + 1, 128-channel block of co' = (2a + b) * Cout + co,
+// ci block), tap sx + 1 of the row.  Fixed order: bit-reproducible.
+struct WgFoldRedK { const float* ws; float* dw; int nslice, gx, tiles_ci, Cout, Cin_real; long long s_co, s_ci, s_tap; int overwrite; };
+__global__ void wgrad_fold_reduce_kernel(WgFoldRedK p) {
+    const int ci4 = (p.Cin_real + 3) / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)9 * p.Cout * ci4) return;
+    const int cq = (int)(i % ci4), rest = (int)(i / ci4);
+    const int co = rest % p.Cout, tap = rest / p.Cout;
+    const int ky = tap / 3 - 1, kx = tap % 3 - 1, ci = cq * 4;
+    const int tiles = (4 * p.Cout / 128) * p.tiles_ci;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        const int sy = (a + ky) >> 1, sx = (b + kx) >> 1;           // (arithmetic shifts: -1 >> 1 = -1)
+        const int irow = sy - a + 1, t = sx + 1;
+        const int cop = ph * p.Cout + co;
+        const int bx = irow * tiles + (cop >> 7) * p.tiles_ci + (ci >> 7);
+        const size_t off = ((size_t)bx * 3 + t) * (128 * 128) + (size_t)(cop & 127) * 128 + (ci & 127);
+        acc += slice_sum4(p.ws, p.nslice, (size_t)p.gx * 3 * (128 * 128), off);
+    }
+    float* d = p.dw + co * p.s_co + ci * p.s_ci + tap * p.s_tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ci + j < p.Cin_real) d[j * p.s_ci] = p.overwrite ? acc[j] : d[j * p.s_ci] + acc[j];
+}
+// its bias gradient: dbias[co] += sum over (phase, slice, filter row, ci tile) of the workgroups' partial column sums, fixed order
+// (block = 32 channels x 32 partial lanes, as wgrad_row_bias_reduce_kernel)
+struct WgFoldBiasK { const float* wsb; float* dbias; int nslice, gx, tiles_ci, Cout; };
+__global__ __launch_bounds__(1024) void wgrad_fold_bias_reduce_kernel(WgFoldBiasK p) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, l = threadIdx.x >> 5, co = blockIdx.x * 32 + c;
+    const int tiles = (4 * p.Cout / 128) * p.tiles_ci, per = 2 * p.tiles_ci, nitem = 4 * p.nslice * per;
+    auto item = [&](int i) __attribute__((always_inline)) -> float {
+        if (i >= nitem || co >= p.Cout) return 0.f;
+        const int ph = i / (p.nslice * per), r0 = i - ph * (p.nslice * per);
+        const int bz = r0 / per, r = r0 - bz * per;
+        const int irow = r / p.tiles_ci, tci = r - irow * p.tiles_ci;
+        const int cop = ph * p.Cout + co;
+        const int bx = irow * tiles + (cop >> 7) * p.tiles_ci + tci;
+        return p.wsb[((size_t)bz * p.gx + bx) * 128 + (cop & 127)];
+    };
+    float a = 0.f;
+    for (int i = l; i < nitem; i += 32 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = item(i + 32 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    red[l][c] = a;
+    __syncthreads();
+    if (l == 0) {
+        for (int j = 1; j < 32; ++j) a += red[j][c];
+        if (co < p.Cout) p.dbias[co] += a;
+    }
+}
+
 }  // namespace
 
 // Validates a weight-gradient request and derives tile shape, grid and row split.
 // mode: 0 = one tap per workgroup (conv_wgrad_kernel), 1 = one filter row per workgroup (conv_wgrad_row_kernel; ta = WM)
-static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit, int& mode) {
+// fold: `d` is the folded request of an x2-upsampled 3 x 3 layer (wgrad_plan below): only the one-wave-per-SIMD 128 x 128 tile serves it
+static int wgrad_plan1(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit, int& mode, bool fold) {
     if (!d || !d->x || !d->dy || !d->dw) return DVD_E_ARG;
     int logH = ilog2_exact(d->H), logW = ilog2_exact(d->W);
     const bool pow2 = logH >= 0 && logW >= 0;
@@ -1270,12 +1356,14 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         // a caller-forced split (msplit > 0: tests) takes the tile whatever the size.
         if (DVD_WG_ROW4 && !d->up2 && ta >= 2 && (d->kw == 3 ? ci128 : (DVD_WG_ROW4 >= 3 && (ta == 4 || ci128)))) {
             int t4 = ta, b4 = 2;
-            if (d->kw == 3) { if (DVD_WG_ROW4 == 1 || d->dbias) t4 = 2; }
+            if (d->kw == 3) { if (DVD_WG_ROW4 == 1 || d->dbias || fold) t4 = 2; }
             else if (ta == 4) b4 = 1;
             const long long wgs = (long long)((d->Cout + t4 * 64 - 1) / (t4 * 64)) * ((d->Cin_real + b4 * 64 - 1) / (b4 * 64)) * d->kt * d->kh * (M / 4096);
             if (wgs >= 224 || d->msplit > 0) { mode = 2; tb = b4; ta = t4; }
         }
     }
+    if (fold && mode != 2) return DVD_E_SHAPE;
+    const int nrow = fold ? 2 : d->kt * d->kh;                   // filter rows per (channel tile, slice) of the filter-row kernels
     p.tiles_co = (d->Cout + ta * 64 - 1) / (ta * 64); p.tiles_ci = (d->Cin_real + tb * 64 - 1) / (tb * 64);
     p.s_co = d->s_co; p.s_ci = d->s_ci; p.s_tap = d->s_tap; p.dbias = d->dbias; p.ws = nullptr;
     p.xcd_remap = 1;
@@ -1297,7 +1385,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         //  chain's kernels no longer leave the side stream the CUs they used to -- fewer, longer slices win on the STEP: 256 503.4 / 503.8,
         //  384 498.1 / 498.1, 512 495.6 / 495.7, 768 497.7 / 498.5, 1024 498.4 / 497.3, 1536 500.4 / 500.3, 3072 501.3 ms, one box)
         constexpr long long tgt_row = 512;
-        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode >= 1 ? d->kt * d->kh : ntaps);
+        const long long base = (long long)p.tiles_co * p.tiles_ci * (mode >= 1 ? nrow : ntaps);
         // one-wave-per-SIMD tiles (one workgroup per CU at a time): ONE round of 256 workgroups -- step at C2, interleaved on one box:
         // one round 451.3 / 451.8 ms, two 452.1 / 452.3, three 454.5 / 454.2 (half the slice workspace per halving) -- two rounds
         // beyond 6 M rows (configs[3], 4x the rows per launch: one round 1802 ms, two 1739)
@@ -1322,7 +1410,8 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     }
     long long rows = (M + msplit - 1) / msplit;
     {   // a workgroup's row slice is addressed with 32-bit byte offsets
-        const long long ldmax = (d->ldx > d->ldy ? d->ldx : d->ldy) * (d->dtype == DVD_BF16 ? 2ll : 4ll);
+        const long long ldy_eff = fold ? 4ll * d->ldy : d->ldy;     // (folded: a slice of input pixels spans four times as many rows of dy)
+        const long long ldmax = (d->ldx > ldy_eff ? d->ldx : ldy_eff) * (d->dtype == DVD_BF16 ? 2ll : 4ll);
         const long long cap = (1ll << 31) / ldmax;
         if (rows > cap) rows = cap;
     }
@@ -1332,7 +1421,7 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
     if (mode == 2 && d->msplit < 1) {
         // the 32-bit offset cap can undo the whole-round rounding above (configs[3]: 3.1 M x 512 -> 512 behind a 1536-wide dy: 5 slices x 80
         // workgroups = 1.56 rounds of one workgroup per CU): fill the last round
-        const long long base = (long long)p.tiles_co * p.tiles_ci * d->kt * d->kh, wg = base * msplit;
+        const long long base = (long long)p.tiles_co * p.tiles_ci * nrow, wg = base * msplit;
         if (wg > 256 && wg % 256 > 0 && wg % 256 < 192) {
             const long long ms2 = ((wg + 255) / 256 * 256) / base;
             if (ms2 > msplit && M / ms2 >= 2048) {
@@ -1342,30 +1431,54 @@ static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int&
         }
     }
     p.rows_per_split = (int)rows;
-    grid = dim3(p.tiles_co * p.tiles_ci * (mode >= 1 ? d->kt * d->kh : ntaps), 1, (unsigned)msplit);
+    grid = dim3(p.tiles_co * p.tiles_ci * (mode >= 1 ? nrow : ntaps), 1, (unsigned)msplit);
+    p.fold = 0; p.cout_f = d->Cout;
     return DVD_OK;
+}
+
+// A 3 x 3 layer over a nearest-x2 upsampled input is planned on the input grid when the folded form applies (see
+// conv_wgrad_row4_kernel<.., FOLD>): whole 64-channel blocks of Cout, 128-wide input-channel tiles, a slice workspace (`may_fold`:
+// the caller supplied one, or is asking for its size) and enough rows for the one-wave-per-SIMD tile.
+static int wgrad_plan(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int& tb, long long& msplit, int& mode, bool may_fold) {
+#ifndef DVD_WG_FOLD
+#define DVD_WG_FOLD 1
+#endif
+    if (DVD_WG_FOLD && may_fold && d && d->up2 && d->dtype == DVD_BF16 && d->kt == 1 && d->kh == 3 && d->kw == 3 && d->T == 1 &&
+        d->Cout % 64 == 0 && d->Cy >= d->Cout && !((d->H | d->W) & 1)) {
+        dvd_wgrad_desc e = *d;
+        e.H = d->H / 2; e.W = d->W / 2; e.up2 = 0;
+        e.Cout = e.Cy = 4 * d->Cout;
+        if (wgrad_plan1(&e, p, grid, ta, tb, msplit, mode, true) == DVD_OK) {
+            const size_t M4 = (size_t)d->frames * d->T * d->H * d->W;
+            p.dy_bytes = ((M4 - 1) * (size_t)d->ldy + d->Cy) * 2;
+            p.fold = 1; p.cout_f = d->Cout;
+            return DVD_OK;
+        }
+    }
+    return wgrad_plan1(d, p, grid, ta, tb, msplit, mode, false);
 }
 
 extern "C" long long dvd_conv_wgrad_ws_floats(const dvd_wgrad_desc* d) {
     WgK p; dim3 grid; int ta, tb, mode; long long msplit;
     if (const long long thin = dvd_wgrad_thin_ws_floats(d)) return thin;       // 3 (8) channels on one side: wgrad_thin.hip
-    if (wgrad_plan(d, p, grid, ta, tb, msplit, mode) != DVD_OK || msplit <= 1) return 0;
+    if (wgrad_plan(d, p, grid, ta, tb, msplit, mode, true) != DVD_OK || (msplit <= 1 && !p.fold)) return 0;
     if (mode >= 1) return msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64) + msplit * (long long)grid.x * (ta * 64);   // + bias partials
     return msplit * (long long)grid.x * (ta * 64) * (tb * 64) + msplit * (long long)p.tiles_co * (ta * 64);      // + bias partials
 }
 
 extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     WgK p; dim3 grid; int ta, tb, mode; long long msplit;
-    const int rc = wgrad_plan(d, p, grid, ta, tb, msplit, mode);
+    const int rc = wgrad_plan(d, p, grid, ta, tb, msplit, mode, d && d->ws != nullptr);
     if (rc != DVD_OK) return rc;
     const int ntaps = d->kt * d->kh * d->kw;
+    const long long Mreal = (long long)d->frames * d->T * d->H * d->W;
     if (d->ws && dvd_wgrad_thin_ws_floats(d)) {    // the thin ends of the networks (stems, RGB layer): taps folded into the matrix dimension
         if (d->overwrite && (d->s_tap != 1 || d->s_ci != ntaps || d->s_co != (long long)d->Cin_real * ntaps)) return DVD_E_ARG;
-        ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, 0, d->relu_in << 1);
+        ProfScope prof(1, 2.0 * (double)Mreal * d->Cout * d->Cin_real * ntaps, stream, (int)Mreal, d->C, d->Cout, ntaps, 0, d->relu_in << 1);
         prof.r.variant = 3;
         return dvd_wgrad_thin(d, stream);
     }
-    if (d->ws && msplit > 1) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw
+    if (d->ws && (msplit > 1 || p.fold)) p.ws = d->ws;         // two-phase reduction; a single slice adds straight into dw (not the folded form)
     const int overwrite = d->overwrite != 0;       // dw = result instead of dw += result (the caller need not zero it)
     if (overwrite) {
         if (d->s_tap != 1 || d->s_ci != ntaps || d->s_co != (long long)d->Cin_real * ntaps) return DVD_E_ARG;   // dense [co][ci][tap] only
@@ -1374,7 +1487,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
     }
     p.wsb = !p.ws ? nullptr : mode >= 1 ? p.ws + msplit * (long long)grid.x * d->kw * (ta * 64) * (tb * 64)
                                         : p.ws + msplit * (long long)grid.x * (ta * 64) * (tb * 64);
-    ProfScope prof(1, 2.0 * (double)p.M * d->Cout * d->Cin_real * ntaps, stream, p.M, d->C, d->Cout, ntaps, (int)msplit,
+    ProfScope prof(1, 2.0 * (double)Mreal * d->Cout * d->Cin_real * ntaps, stream, (int)Mreal, d->C, d->Cout, ntaps, (int)msplit,
                    d->up2 | (d->relu_in << 1));
     hipStream_t st = (hipStream_t)stream;
     prof.r.variant = mode == 2 ? 4 : mode == 1 ? 1 : 2;        // (dvd_prof_report_variants: 1 = 8-wave filter-row tiles, 2 = one tap, 3 = thin ends, 4 = one wave per SIMD)
@@ -1392,6 +1505,17 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
 #define LAUNCH_ROW4(KW_, AW_, BW_, WCO_, WCI_, DEPTH_)                                                                        \
             do { if (d->relu_in) conv_wgrad_row4_kernel<KW_, AW_, BW_, WCO_, WCI_, true, DEPTH_><<<grid, 256, 0, st>>>(p);       \
                  else conv_wgrad_row4_kernel<KW_, AW_, BW_, WCO_, WCI_, false, DEPTH_><<<grid, 256, 0, st>>>(p); } while (0)
+            if (p.fold) {
+                if (d->relu_in) conv_wgrad_row4_kernel<3, 4, 1, 1, 4, true, 2, true><<<grid, 256, 0, st>>>(p);
+                else conv_wgrad_row4_kernel<3, 4, 1, 1, 4, false, 2, true><<<grid, 256, 0, st>>>(p);
+                WgFoldRedK r{p.ws, p.dw, (int)msplit, (int)grid.x, p.tiles_ci, d->Cout, p.Cin_real, p.s_co, p.s_ci, p.s_tap, overwrite};
+                wgrad_fold_reduce_kernel<<<cdiv(9ll * d->Cout * ((p.Cin_real + 3) / 4), 256), 256, 0, st>>>(r);
+                if (p.dbias) {
+                    WgFoldBiasK b{p.wsb, p.dbias, (int)msplit, (int)grid.x, p.tiles_ci, d->Cout};
+                    wgrad_fold_bias_reduce_kernel<<<cdiv(d->Cout, 32), 1024, 0, st>>>(b);
+                }
+                return launch_status();
+            }
             if (d->kw == 3) { if (ta == 4) LAUNCH_ROW4(3, 4, 2, 2, 2, 2); else LAUNCH_ROW4(3, 4, 1, 1, 4, DVD_ROW4_DEPTH); }
             else            { if (ta == 4) LAUNCH_ROW4(5, 4, 1, 2, 2, 2); else LAUNCH_ROW4(5, 4, 1, 1, 4, 2); }
 #undef LAUNCH_ROW4

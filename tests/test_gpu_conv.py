@@ -68,6 +68,13 @@ CASES = [
     (2, 72, 136, (16, 64), (3, 3), False, False),    # W = 64: two 32-pixel segments per line, H != W, ragged input tile
     (3, 192, 264, (32, 32), (3, 3), False, False),   # W = 32, 3 x 2 tiles, several row slices
     (1, 128, 128, (3, 16, 16), (3, 3, 3), False, False),   # 3-D, T = 3
+    # x2-upsampled input folded onto the input grid (round 6: conv_wgrad_row4_kernel<.., FOLD>, taken with a forced split here):
+    # the line geometries of the INPUT grid, phase blocks of 64 / 128 / 192 channels inside the 128-channel tiles
+    (4, 128, 64, (64, 64), (3, 3), True, True),      # input lines of 32 pixels: one line per step; a tile = two column phases
+    (2, 72, 128, (32, 32), (3, 3), True, False),     # 16-pixel input lines: two per step; a tile = one phase; ragged input tile
+    (3, 128, 192, (16, 16), (3, 3), True, True),     # 8-pixel input lines: four per step; tiles straddle the column phases
+    (6, 200, 64, (8, 8), (3, 3), True, False),       # 4 x 4 input frames: a step = two frames; two input-channel tiles
+    (2, 128, 64, (16, 128), (3, 3), True, True),     # 64-pixel input lines: two segments per line, H != W
     # nine-tap 3 x 3 weight-gradient kernel (Cout > 64): the three line geometries of its footprint
     (5, 40, 136, (8, 8), (3, 3), False, False),      # W = 8: four lines per step + 2 halo lines of 10 rows
     (3, 72, 200, (16, 16), (3, 3), False, True),     # W = 16: two lines + 2, two in-channel tiles, ReLU

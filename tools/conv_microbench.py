@@ -46,6 +46,9 @@ SHAPES = [   # frames, S, Cin, Cout, k, split-K slabs?
     (3072, 4, 256, 1536, 5, False),
     (3008, 4, 256, 256, 3, False),
     (3072, 4, 256, 256, 3, False),
+    (3072, 64, 128, 64, 3, False, True),   # 37..39: 3 x 3 over a nearest-x2 upsampled input (GResBlock conv1), S = the OUTPUT size
+    (3072, 32, 256, 128, 3, False, True),
+    (3072, 16, 256, 256, 3, False, True),
 ]
 
 
@@ -78,7 +81,19 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     dev, dt = "cuda", torch.bfloat16
     sel = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(SHAPES))
-    for F_, S, Cin, Cout, k, slabs in [SHAPES[i] for i in sel]:
+    for shp in [SHAPES[i] for i in sel]:
+        F_, S, Cin, Cout, k, slabs = shp[:6]
+        up2 = len(shp) > 6 and shp[6]
+        if up2:
+            if what in ("wgrad", "all"):
+                x = torch.randn(F_, S // 2, S // 2, Cin, device=dev).to(dt)
+                dy = torch.randn(F_, S, S, Cout, device=dev).to(dt)
+                dw = torch.zeros(Cout, Cin, k, k, device=dev)
+                db = torch.zeros(Cout, device=dev) if os.environ.get("WG_BIAS") == "1" else None
+                M, fl = F_ * S * S, 2.0 * F_ * S * S * Cout * Cin * k * k
+                ms = bench(lambda: K.conv_wgrad(x, dy, dw, (k, k), Cout, Cin, dbias=db, up2=True), max(2, iters // 3))
+                print(f"wgrad M={M:8d} C={Cin:5d} Cout={Cout:5d} k={k} up2      : {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF/s", flush=True)
+            continue
         x = torch.randn(F_, S, S, Cin, device=dev).to(dt)
         pk = K.PackedConv(dt, Cout, Cin, (k, k), dev).fill(torch.randn(Cout, Cin, k, k, device=dev) * 0.05)
         M = F_ * S * S
