@@ -527,6 +527,27 @@ __global__ void fragment_major_kernel(FragK p) {
     if (co < p.Cout && ci < p.C) v = *reinterpret_cast<const u32x4*>(p.w + ((size_t)tap * p.Cout + co) * p.C + ci);   // C % 8 == 0
     *reinterpret_cast<u32x4*>(p.wq + i * 8) = v;
 }
+// n images in one launch (whole blocks per item, as pack_weight_batched_kernel)
+constexpr int kFragBatch = 32;
+struct FragBatchK { FragK it[kFragBatch]; int first[kFragBatch + 1]; int n; };
+__global__ void fragment_major_batched_kernel(FragBatchK b) {
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
+    const FragK& p = b.it[j];
+    const long long n = (long long)p.ntaps * p.kchunks * p.nb32 * 2 * 64;
+    const long long i = (long long)((int)blockIdx.x - b.first[j]) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int l = (int)(i & 63);
+    long long r = i >> 6;
+    const int kk = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r % p.nb32); r /= p.nb32;
+    const int cc = (int)(r % p.kchunks);
+    const int tap = (int)(r / p.kchunks);
+    const int co = nb * 32 + (l & 31), ci = cc * 32 + (kk * 2 + (l >> 5)) * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (co < p.Cout && ci < p.C) v = *reinterpret_cast<const u32x4*>(p.w + ((size_t)tap * p.Cout + co) * p.C + ci);
+    *reinterpret_cast<u32x4*>(p.wq + i * 8) = v;
+}
 
 }  // namespace
 
@@ -588,5 +609,29 @@ extern "C" int dvd_conv_fragment_major(int dtype, const void* w, void* wq, int n
     FragK p{(const bf16_t*)w, (bf16_t*)wq, ntaps, Cout, C, (C + 31) / 32, (Cout + 127) / 128 * 4};
     const long long n = (long long)ntaps * p.kchunks * p.nb32 * 128;
     fragment_major_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p);
+    return launch_status();
+}
+
+extern "C" int dvd_conv_fragment_major_batched(int dtype, const dvd_frag_item* items, int n, void* stream) {
+    if (!items || n <= 0) return DVD_E_ARG;
+    if (dtype != DVD_BF16) return DVD_E_SHAPE;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].w || !items[i].wq || items[i].ntaps <= 0 || items[i].Cout <= 0 || items[i].C <= 0) return DVD_E_ARG;
+        if (items[i].C & 7) return DVD_E_SHAPE;
+    }
+    for (int i0 = 0; i0 < n; i0 += kFragBatch) {
+        FragBatchK b;
+        b.n = n - i0 < kFragBatch ? n - i0 : kFragBatch;
+        long long blocks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const dvd_frag_item& t = items[i0 + j];
+            b.it[j] = FragK{(const bf16_t*)t.w, (bf16_t*)t.wq, t.ntaps, t.Cout, t.C, (t.C + 31) / 32, (t.Cout + 127) / 128 * 4};
+            b.first[j] = (int)blocks;
+            blocks += cdiv((long long)t.ntaps * b.it[j].kchunks * b.it[j].nb32 * 128, 256);
+        }
+        if (blocks >= (1ll << 31)) return DVD_E_SHAPE;
+        b.first[b.n] = (int)blocks;
+        fragment_major_batched_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(b);
+    }
     return launch_status();
 }

@@ -585,6 +585,32 @@ __global__ void pack_weight_kernel(PackK p) {
     }
 }
 
+// n packs in one launch: block b serves item j with first[j] <= b < first[j + 1] (whole blocks per item)
+constexpr int kPackBatch = 24;
+struct PackBatchK { PackK it[kPackBatch]; int first[kPackBatch + 1]; int n; };
+template <typename T>
+__global__ void pack_weight_batched_kernel(PackBatchK b) {
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
+    const PackK& p = b.it[j];
+    const long long n = (long long)p.Cout * p.Cip * p.ntaps;
+    const long long i = (long long)((int)blockIdx.x - b.first[j]) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int tap = (int)(i % p.ntaps);
+    const long long r = i / p.ntaps;
+    const int ci = (int)(r % p.Cip), co = (int)(r / p.Cip);
+    float v = 0.f;
+    if (ci < p.Cin) {
+        v = p.w[((size_t)co * p.ci_tot + p.ci_off + ci) * p.ntaps + tap];
+        if (p.sigma) v = v / *p.sigma;
+    }
+    if (p.wf) stf(reinterpret_cast<T*>(p.wf) + ((size_t)tap * p.co_tot_f + p.co_off + co) * p.Cip + ci, v);
+    if (p.wd) {
+        const int ftap = p.ntaps - 1 - tap;
+        stf(reinterpret_cast<T*>(p.wd) + ((size_t)ftap * p.Cip + ci) * p.co_tot_d + p.co_off + co, v);
+    }
+}
+
 }  // namespace
 
 // ============================================================================ optional profiling
@@ -891,5 +917,35 @@ extern "C" int dvd_pack_conv_weight(int dtype, const float* w, const float* sigm
     if (dtype == DVD_BF16) pack_weight_kernel<bf16_t><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p);
     else if (dtype == DVD_F32) pack_weight_kernel<float><<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p);
     else return DVD_E_ARG;
+    return launch_status();
+}
+
+extern "C" int dvd_pack_conv_weight_batched(int dtype, const dvd_pack_item* items, int n, void* stream) {
+    if (!items || n <= 0) return DVD_E_ARG;
+    if (dtype != DVD_BF16 && dtype != DVD_F32) return DVD_E_ARG;
+    for (int i = 0; i < n; ++i) {           // validate everything before the first launch
+        const dvd_pack_item& t = items[i];
+        if (!t.w || (!t.wf && !t.wd) || t.Cout <= 0 || t.Cin <= 0 || t.ntaps != t.kt * t.kh * t.kw) return DVD_E_ARG;
+        const int ci_off = t.ci_tot <= 0 ? 0 : t.ci_off, ci_tot = t.ci_tot <= 0 ? t.Cin : t.ci_tot;
+        if (ci_off < 0 || ci_off + t.Cin > ci_tot) return DVD_E_ARG;
+        if ((t.Cip & 7) || t.Cip < t.Cin || (t.wd && (t.co_tot_d & 7))) return DVD_E_SHAPE;
+    }
+    for (int i0 = 0; i0 < n; i0 += kPackBatch) {
+        PackBatchK b;
+        b.n = n - i0 < kPackBatch ? n - i0 : kPackBatch;
+        long long blocks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const dvd_pack_item& t = items[i0 + j];
+            const int ci_off = t.ci_tot <= 0 ? 0 : t.ci_off, ci_tot = t.ci_tot <= 0 ? t.Cin : t.ci_tot;
+            b.it[j] = PackK{t.w, t.sigma, (char*)t.wf, (char*)t.wd, t.Cout, t.Cin, t.ntaps, t.Cip, t.co_off, t.co_tot_f, t.co_tot_d,
+                            t.kt, t.kh, t.kw, ci_off, ci_tot};
+            b.first[j] = (int)blocks;
+            blocks += cdiv((long long)t.Cout * t.Cip * t.ntaps, 256);
+        }
+        if (blocks >= (1ll << 31)) return DVD_E_SHAPE;
+        b.first[b.n] = (int)blocks;
+        if (dtype == DVD_BF16) pack_weight_batched_kernel<bf16_t><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(b);
+        else pack_weight_batched_kernel<float><<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(b);
+    }
     return launch_status();
 }

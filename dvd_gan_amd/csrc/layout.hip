@@ -120,7 +120,7 @@ extern "C" int dvd_clip_to_tensor(const unsigned char* src, const unsigned char*
     return launch_status();
 }
 
-extern "C" int dvd_abi_version(void) { return 12; }
+extern "C" int dvd_abi_version(void) { return 13; }
 extern "C" int dvd_struct_size(int which) {
     switch (which) {
         case DVD_STRUCT_CONV: return (int)sizeof(dvd_conv_desc);
@@ -128,6 +128,8 @@ extern "C" int dvd_struct_size(int which) {
         case DVD_STRUCT_GRU: return (int)sizeof(dvd_gru_desc);
         case DVD_STRUCT_SN_ITEM: return (int)sizeof(dvd_sn_item);
         case DVD_STRUCT_GRU_STACK: return (int)sizeof(dvd_gru_stack_desc);
+        case DVD_STRUCT_PACK_ITEM: return (int)sizeof(dvd_pack_item);
+        case DVD_STRUCT_FRAG_ITEM: return (int)sizeof(dvd_frag_item);
         default: return -1;
     }
 }

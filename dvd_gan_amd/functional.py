@@ -560,6 +560,9 @@ class ConvGRUStack(Function):
         sd.n_layers, sd.layer_policy, sd.run = nl, GRU_STACK_LAYER_POLICY, 0
         keep, layers = [], []
         inp = x
+        # the 6 gate packs of every layer and their fragment-major images (the backward pass's too unless `infer`) in TWO launches for
+        # the whole ConvGRU (K.PackBatch) instead of 12-15 per layer, all of them in front of the first convolution
+        pb, packs = K.PackBatch(), []
         for l, (wu, bu, wr, br, wo, bo) in enumerate(wts):
             hid, ctot, k = wu.shape[0], wu.shape[1], wu.shape[-1]
             cin = ctot - hid
@@ -567,9 +570,19 @@ class ConvGRUStack(Function):
             pur = K.PackedConv(dtype, 2 * hid, hid, (k, k), dev, covered=True)
             po = K.PackedConv(dtype, hid, hid, (k, k), dev, covered=True)
             for g, w in enumerate((wu, wr, wo)):
-                px.fill(w, co_off=g * hid, ci_off=0)
-            pur.fill(wu, co_off=0, ci_off=cin).fill(wr, co_off=hid, ci_off=cin)
-            po.fill(wo, ci_off=cin)
+                pb.fill(px, w, co_off=g * hid, ci_off=0)
+            pb.fill(pur, wu, co_off=0, ci_off=cin).fill(pur, wr, co_off=hid, ci_off=cin)
+            pb.fill(po, wo, ci_off=cin)
+            for pk in (px, pur, po):
+                pb.fragment_major(pk, "wf")
+                if not infer and (pk is not px or l > 0 or ctx.needs_input_grad[0]):
+                    pb.fragment_major(pk, "wd")
+            packs.append((px, pur, po))
+        pb.run()
+        for l, (wu, bu, wr, br, wo, bo) in enumerate(wts):
+            hid, ctot, k = wu.shape[0], wu.shape[1], wu.shape[-1]
+            cin = ctot - hid
+            px, pur, po = packs[l]
             bias3 = torch.cat([bu, br, bo])
             if l == 0:      # the first layer's input is known for every step: one batched convolution, off the chain
                 gx = K.conv_forward(x, px.wf, (k, k), 3 * hid, bias=bias3, wq=lambda: px.fragment_major("wf"))

@@ -4,6 +4,7 @@ Internal activation layout: channels-last, [frames, (T,) H, W, Cp] with Cp = cha
 multiple of 8, storage dtype torch.float32 (exact mode) or torch.bfloat16.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -76,6 +77,9 @@ class PackedConv:
     def fragment_major(self, which="wf"):
         """The forward ("wf") or backward-data ("wd") image once more in fragment-major order (dvd_conv_fragment_major), for
         the convolution kernel that reads its weight operand straight from L2; built on first use, after the last fill()."""
+        wants = getattr(self, "wants", None)
+        if wants is not None:
+            wants.add(which)              # (the owner prepares this image ahead of time from the next forward on: sn_layers.prefetch_spectral_norm)
         q = getattr(self, which + "q", None)
         if q is None:
             src = getattr(self, which)
@@ -95,6 +99,63 @@ class PackedConv:
             self.cout, self.cop, L.ptr(self.wf), L.ptr(self.wd), self.k[0], self.k[1], self.k[2],
             ci_off, w.shape[1], L.stream()))
         return self
+
+
+PACK_BATCH = os.environ.get("DVD_PACK_BATCH", "1") != "0"
+
+
+class PackBatch:
+    """Deferred PackedConv.fill / fragment_major calls issued as ONE launch each (dvd_pack_conv_weight_batched,
+    dvd_conv_fragment_major_batched): the 18 gate packs and up to 18 fragment-major images of a three-layer ConvGRU were 36+
+    launches of 6-18 us on the stream in front of its first convolution."""
+
+    def __init__(self):
+        self.fills, self.frags, self.dtype = [], [], None
+
+    def fill(self, pk, w, sigma=None, co_off=0, ci_off=0):
+        assert w.is_contiguous() and w.dtype == torch.float32
+        it = L.PackItem()
+        it.w, it.sigma, it.wf, it.wd = w.data_ptr(), L.ptr(sigma), L.ptr(pk.wf), L.ptr(pk.wd)
+        it.Cout, it.Cin, it.ntaps, it.Cip, it.co_off = w.shape[0], pk.cin, pk.ntaps, pk.cip, co_off
+        it.co_tot_f, it.co_tot_d = pk.cout, pk.cop
+        it.kt, it.kh, it.kw = pk.k
+        it.ci_off, it.ci_tot = ci_off, w.shape[1]
+        assert self.dtype in (None, pk.wf.dtype)
+        self.dtype = pk.wf.dtype
+        self.fills.append((it, w, sigma, pk))
+        return self
+
+    def fragment_major(self, pk, which="wf"):
+        """Schedules the fragment-major image of `pk.<which>` (built by run(), after the fills) and returns the tensor it will be in."""
+        q = getattr(pk, which + "q", None)
+        if q is None:
+            src = getattr(pk, which)
+            cout, c = (pk.cout, pk.cip) if which == "wf" else (pk.cip, pk.cop)
+            n = L.lib().dvd_conv_fragment_major_bytes(pk.ntaps, cout, c)
+            q = torch.empty(n // 2, dtype=src.dtype, device=src.device)
+            it = L.FragItem()
+            it.w, it.wq, it.ntaps, it.Cout, it.C = src.data_ptr(), q.data_ptr(), pk.ntaps, cout, c
+            self.frags.append((it, src, q))
+            setattr(pk, which + "q", q)
+        return q
+
+    def run(self):
+        dt_ = L.BF16 if self.dtype == torch.bfloat16 else L.F32
+        if not PACK_BATCH:                # A/B aid: one launch per item, as before round 6
+            for it, *_ in self.fills:
+                vp = C.c_void_p
+                L.check(L.lib().dvd_pack_conv_weight(dt_, vp(it.w), vp(it.sigma), it.Cout, it.Cin, it.ntaps, it.Cip, it.co_off, it.co_tot_f,
+                                                     it.co_tot_d, vp(it.wf), vp(it.wd), it.kt, it.kh, it.kw, it.ci_off, it.ci_tot, L.stream()))
+            for it, *_ in self.frags:
+                L.check(L.lib().dvd_conv_fragment_major(L.BF16, C.c_void_p(it.w), C.c_void_p(it.wq), it.ntaps, it.Cout, it.C, L.stream()))
+        else:
+            if self.fills:
+                arr = (L.PackItem * len(self.fills))(*[f[0] for f in self.fills])
+                L.check(L.lib().dvd_pack_conv_weight_batched(dt_, arr, len(self.fills), L.stream()))
+            if self.frags:
+                arr = (L.FragItem * len(self.frags))(*[f[0] for f in self.frags])
+                L.check(L.lib().dvd_conv_fragment_major_batched(L.BF16, arr, len(self.frags), L.stream()))
+        self.fills, self.frags = [], []
 
 
 # ------------------------------------------------------------------ convolution

@@ -62,7 +62,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 BN_NREP = 16            # DVD_BN_NREP of include/dvdgan_hip.h
 SN_SCRATCH = 512        # DVD_SN_SCRATCH
 
@@ -152,5 +152,16 @@ class SnItem(C.Structure):              # == dvd_sn_item
                 ("blk_wtu", C.c_int), ("blk_wv", C.c_int), ("blk_pack", C.c_int), ("pad_", C.c_int)]
 
 
+class PackItem(C.Structure):            # == dvd_pack_item
+    _fields_ = [("w", C.c_void_p), ("sigma", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p),
+                ("Cout", C.c_int), ("Cin", C.c_int), ("ntaps", C.c_int), ("Cip", C.c_int), ("co_off", C.c_int),
+                ("co_tot_f", C.c_int), ("co_tot_d", C.c_int), ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("ci_off", C.c_int), ("ci_tot", C.c_int)]
+
+
+class FragItem(C.Structure):            # == dvd_frag_item
+    _fields_ = [("w", C.c_void_p), ("wq", C.c_void_p), ("ntaps", C.c_int), ("Cout", C.c_int), ("C", C.c_int)]
+
+
 # dvd_struct_size(which) -> ctypes mirror (DVD_STRUCT_* of include/dvdgan_hip.h)
-STRUCT_MIRRORS = {0: ConvDesc, 1: WgradDesc, 2: GruDesc, 3: SnItem, 4: GruStackDesc}
+STRUCT_MIRRORS = {0: ConvDesc, 1: WgradDesc, 2: GruDesc, 3: SnItem, 4: GruStackDesc, 5: PackItem, 6: FragItem}

@@ -78,6 +78,7 @@ class SpectralNormConv(nn.Module):
         self.train_weights = True          # False: treat weights as constants (G step through D)
 
         self._pre = None                   # (sigma, pack, event) prepared on the SN side stream for the next forward
+        self._frag_wants = set()           # fragment-major images ("wf" / "wd") the layer's convolutions asked for so far
 
     def _alloc(self, dtype, device):
         return (torch.empty(1, dtype=torch.float32, device=device),
@@ -98,6 +99,7 @@ class SpectralNormConv(nn.Module):
         else:
             sigma, pack = self._alloc(x.dtype, x.device)
             self._sn_and_pack(sigma, pack)
+        pack.wants = self._frag_wants
         spec = Fn.ConvSpec(self.ksize, self.cout, self.cin, act=act, up2=up2, relu_in=relu_in,
                            sn=(m.weight_u.data, m.weight_v.data))
         spec.sigma = sigma
@@ -141,11 +143,20 @@ def prefetch_spectral_norm(net, dtype):
         host = torch.empty(C.sizeof(items), dtype=torch.uint8, pin_memory=True)
         C.memmove(host.data_ptr(), C.addressof(items), C.sizeof(items))
         scratch = torch.empty(max(1, nfl.value), dtype=torch.float32, device=dev)
+        # the fragment-major images each layer's convolutions used in earlier steps, in one launch behind the packs (they were ~100
+        # launches of 6 us per step on the main stream, one in front of the layer's convolution); buffers allocated in main-stream order
+        pb = K.PackBatch()
+        if dtype == torch.bfloat16 and K.PACK_BATCH:
+            for m, (sigma, pack) in zip(mods, bufs):
+                for which in sorted(m._frag_wants):
+                    if getattr(pack, which) is not None:
+                        pb.fragment_major(pack, which)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             table = host.to(dev, non_blocking=True)
             L.check(L.lib().dvd_sn_batched(items, C.c_void_p(table.data_ptr()), n, C.c_void_p(scratch.data_ptr()),
                                            C.c_void_p(side.cuda_stream)))
+            pb.run()
             ev = torch.cuda.Event()
             ev.record(side)
         scratch.record_stream(side)

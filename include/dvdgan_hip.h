@@ -41,7 +41,7 @@ extern "C" {
 
 int dvd_abi_version(void);              /* bumps when a signature changes                      */
 /* Layout handshake: sizeof() of descriptor struct `which` AS THIS LIBRARY WAS COMPILED (0 = dvd_conv_desc, 1 = dvd_wgrad_desc,
- * 2 = dvd_gru_desc, 3 = dvd_sn_item, 4 = dvd_gru_stack_desc; -1 = unknown index).  A binding compares it with the size of its own
+ * 2 = dvd_gru_desc, 3 = dvd_sn_item, 4 = dvd_gru_stack_desc, 5 = dvd_pack_item, 6 = dvd_frag_item; -1 = unknown index).  A binding compares it with the size of its own
  * mirror of the struct at load time (dvd_gan_amd/lib.py does; tests/test_abi_cpu.py also checks the stub printed in
  * INTEGRATION.md): a descriptor that grew on one side only is caught before the library reads past the caller's struct.
  * The reference boundary these structs stand in for is the nn.Module constructor / forward argument lists
@@ -51,6 +51,8 @@ int dvd_abi_version(void);              /* bumps when a signature changes       
 #define DVD_STRUCT_GRU 2
 #define DVD_STRUCT_SN_ITEM 3
 #define DVD_STRUCT_GRU_STACK 4
+#define DVD_STRUCT_PACK_ITEM 5
+#define DVD_STRUCT_FRAG_ITEM 6
 int dvd_struct_size(int which);
 /* Optional measurement aid for bench.py: bracket every conv launch with HIP events on its stream.
  * kind 0 = conv_igemm (forward / backward-data), 1 = conv_wgrad.  Report drains the records,
@@ -120,6 +122,9 @@ int dvd_conv_pool2_ok(const dvd_conv_desc* d);
  * pack of dvd_pack_conv_weight ([ntaps][Cout][C], bf16, C % 8 == 0).  Re-run after every re-pack (spectral norm: every forward). */
 long long dvd_conv_fragment_major_bytes(int ntaps, int Cout, int C);
 int dvd_conv_fragment_major(int dtype, const void* w, void* wq, int ntaps, int Cout, int C, void* stream);
+/* n images in one launch per 32 items (ABI 13; `items`: HOST array, copied into the kernel arguments): the packs of a whole ConvGRU. */
+typedef struct { const void* w; void* wq; int ntaps, Cout, C; } dvd_frag_item;
+int dvd_conv_fragment_major_batched(int dtype, const dvd_frag_item* items, int n, void* stream);
 int dvd_conv_wants_fragment_major(const dvd_conv_desc* d);     /* 0 = no, 1 = fragment-major image, 2 / 3 = the thin-input / thin-output image below */
 /* 3 x 3 (x 3) convolutions from 3 (padded to 8) input channels to 64 output channels (the discriminator stems, the backward-data
  * pass of the RGB layer) fold their KW taps into the K dimension; they take, in `wq`, this image of their [kt*9][64][8] pack:
@@ -171,6 +176,14 @@ int dvd_pack_conv_weight(int dtype, const float* w, const float* sigma, int Cout
                          int kt, int kh, int kw, int ci_off, int ci_tot, void* stream);
 /* ci_off/ci_tot: the master tensor is [Cout][ci_tot][ntaps] and only input channels
  * [ci_off, ci_off+Cin) are packed (x-part / h-part of a ConvGRU gate, ConvGRU.py:16-18). */
+/* The same for n requests in ONE launch per 24 items (ABI 13): the x-part / h-part packs of the three gates of every layer of a
+ * ConvGRU (Module/ConvGRU.py:16-18, :104-133: 18 fills per three-layer ConvGRU) were 18 launches of ~18 us in front of its first
+ * convolution.  `items` is a HOST array (copied into the kernel arguments); fields as the arguments of dvd_pack_conv_weight. */
+typedef struct {
+    const float* w; const float* sigma; void* wf; void* wd;
+    int Cout, Cin, ntaps, Cip, co_off, co_tot_f, co_tot_d, kt, kh, kw, ci_off, ci_tot;
+} dvd_pack_item;
+int dvd_pack_conv_weight_batched(int dtype, const dvd_pack_item* items, int n, void* stream);
 
 /* Layout / dtype conversion at the module boundary (reference tensors are NCHW-style fp32):
  *   to_cl:   src fp32 [F][C][P]  -> dst [F][P][Cp]  (pad channels zero-filled)

@@ -45,7 +45,7 @@ def test_descriptor_layouts_match_the_library():
     import ctypes as C
     from dvd_gan_amd import lib as L
     lib = L.lib()
-    assert set(L.STRUCT_MIRRORS) == {0, 1, 2, 3, 4}
+    assert set(L.STRUCT_MIRRORS) == {0, 1, 2, 3, 4, 5, 6}
     for which, mirror in L.STRUCT_MIRRORS.items():
         assert lib.dvd_struct_size(which) == C.sizeof(mirror), (which, mirror.__name__)
     assert lib.dvd_struct_size(99) == -1
