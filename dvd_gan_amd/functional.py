@@ -695,6 +695,10 @@ class ConvGRUStack(Function):
                 xin = per[l - 1][3].view(T * B, S1, S2, dims[l - 1][0])          # the layer below's states
             grads, dbl = _gru_gate_wgrads(xin, dgx, dg, h_all, hr_all, h0, ctx.params[l], (T, B, S1, S2, hid, cin, k), (wu, wr, wo))
             out += [grads[0], dbl[0], grads[1], dbl[1], grads[2], dbl[2]]
+            # this layer's d(pre-activations) are done with once its weight-gradient launches are queued (the side stream holds them
+            # through record_stream): release them layer by layer instead of keeping every layer's [T*B,S,S,3h] until the return
+            dg = dgx = None
+            dgs[l] = carries[l] = dh_mid[l] = None
         dh0s = []
         for l in range(nl):
             h0 = per[l][8]

@@ -102,6 +102,10 @@ class PackedConv:
 
 
 PACK_BATCH = os.environ.get("DVD_PACK_BATCH", "1") != "0"
+# timing-only experiment (WRONG results): 1 = BN statistics from 4096 rows, 2 = CBN backward sums from two frames -- what folding
+# those two passes into the neighbouring convolutions' epilogues could return at most (profiles/HISTORY.md, round 6)
+EXP_CBN = int(os.environ.get("DVD_EXP_CBN", "0"))
+EXP_SKIP = int(os.environ.get("DVD_EXP_SKIP", "0"))      # 1 = skip the 1 x 1 convolutions on >= 128 k rows (garbage results)
 
 
 class PackBatch:
@@ -267,6 +271,8 @@ def conv_forward(x, wpack, ksize, cout, *, bias=None, res=None, mask=None, act=L
         alloc = torch.zeros if cp_out != cout else torch.empty
         out = alloc(shape, dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     d.out, d.ldo = out.data_ptr(), out.shape[-1]
+    if EXP_SKIP & 1 and k == (1, 1, 1) and M >= (1 << 17):       # timing experiment: the large 1 x 1 convolutions are not launched
+        return out
     L.check(L.lib().dvd_conv_forward(C.byref(d), L.stream()))
     return out
 
@@ -330,6 +336,8 @@ def bn_stats(x, C_real, training, eps, momentum, run_mean, run_var, replicas=Non
         if training:
             if sums is None:
                 sums = torch.zeros(L.BN_NREP * 2 * C_real, dtype=torch.float64, device=x.device)
+            if EXP_CBN & 1:               # timing experiment (wrong statistics): the pass over x reads 4096 rows only
+                rows = min(rows, 4096)
             L.check(L.lib().dvd_bn_stats(L.dt(x), L.ptr(x), _ll(rows), C_real, ld, L.ptr(sums), L.stream()))
             if replicas is not None:
                 replicas[1](sums)
@@ -362,6 +370,14 @@ def cbn_backward(g, a, x, C_real, mean, rstd, gb, samp, relu, replicas=None):
     dgb = torch.zeros_like(gb)
     s12 = torch.empty(2 * C_real, dtype=torch.float32, device=x.device)
     part = torch.empty(L.lib().dvd_cbn_backward_ws_floats(_ll(frames), P, C_real), dtype=torch.float32, device=x.device)   # fixed-order dgb
+    if EXP_CBN & 2 and replicas is None:      # timing experiment (wrong sums): the reduce pass reads two frames only
+        L.check(L.lib().dvd_cbn_backward_reduce(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), _ll(min(frames, 2)), P, C_real, x.shape[-1],
+                                                L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb), L.ptr(s12),
+                                                int(relu), L.ptr(part), L.stream()))
+        L.check(L.lib().dvd_cbn_backward_apply(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
+                                               x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), L.ptr(s12),
+                                               _ll(frames * P), int(relu), L.stream()))
+        return dx, dgb
     if replicas is None:
         L.check(L.lib().dvd_cbn_backward(L.dt(x), L.ptr(g), L.ptr(a), L.ptr(x), L.ptr(dx), _ll(frames), P, C_real,
                                          x.shape[-1], L.ptr(mean), L.ptr(rstd), L.ptr(gb), L.ptr(samp), B, L.ptr(dgb),

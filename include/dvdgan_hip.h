@@ -159,7 +159,11 @@ typedef struct {
                                   without it the centre-tap workgroups add with atomics), co < Cout; NULL = skip */
     float* ws;                 /* optional workspace of dvd_conv_wgrad_ws_floats(d) floats: row slices write
                                   their partial tiles there with plain stores and a second kernel reduces
-                                  them into dw (deterministic, no atomics).  NULL = fp32 atomics on dw      */
+                                  them into dw (deterministic, no atomics).  NULL = fp32 atomics on dw.
+                                  With a workspace, 3 x 3 layers over a x2-upsampled input (up2, GResBlock.py:57-58) whose
+                                  Cout is a multiple of 64 are worked on the INPUT grid (four dy phases as output channels,
+                                  2 / 3 of the products; same bf16 products, another fp32 summation order); without one
+                                  they take the direct x2 tiles                                              */
     int overwrite;             /* 1: dw = result instead of dw += result (dense [co][ci][tap] dw only): no zero fill by the caller */
 } dvd_wgrad_desc;
 int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream);
