@@ -367,3 +367,39 @@ def test_weights_from_l2_kernel_3d_taps():
     pk = K.PackedConv(torch.bfloat16, 64, 64, (3, 3, 3), DEV).fill(torch.randn(64, 64, 3, 3, 3, device=DEV) * 0.05)
     ref = K.conv_forward(x, pk.wf, (3, 3, 3), 64).clone()
     assert torch.equal(ref, K.conv_forward(x, pk.wf, (3, 3, 3), 64, wq=pk.fragment_major("wf")))
+
+
+@pytest.mark.parametrize("case", [(768, 128, 64, 64, True), (768, 256, 128, 32, False), (3072, 256, 256, 16, True)])
+def test_upsampled_weight_gradient_on_the_planners_own_split(case):
+    """The weight gradient of a 3 x 3 convolution over a nearest-x2 upsampled input (GResBlock.py:57-58) at sizes where the planner
+    itself takes the folded form (round 6: conv_wgrad_row4_kernel<.., FOLD> on the input grid, four dy phases as output channels;
+    the CASES above force it with msplit) -- generator stages 32 -> 64, 16 -> 32 and 8 -> 16 pixels at a quarter / the full batch:
+    against an fp64 restatement of the same sums on the bf16-ROUNDED operands (only the kernels' fp32 summation order differs: 1e-5
+    as for the other sliced checks), weight and bias gradient, accumulate and overwrite mode."""
+    from dvd_gan_amd import kern as K
+    F_, Cin, Cout, S, relu_in = case
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(1234 + S)
+    x = bf(torch.randn(F_, Cin, S // 2, S // 2, device=dev, generator=g))
+    gy = bf(torch.randn(F_, Cout, S, S, device=dev, generator=g) * 0.1)
+    # fp64 reference, tap by tap, in chunks of frames: dw[co][ci][ky][kx] = sum over (f, y, x) of gy[f][co][y][x] * xin[f][ci][y + ky - 1][x + kx - 1]
+    dw_ref = torch.zeros(Cout, Cin, 3, 3, device=dev, dtype=torch.float64)
+    db_ref = gy.double().sum((0, 2, 3))
+    for f0 in range(0, F_, 64):
+        xin = F.interpolate(F.relu(x[f0:f0 + 64]) if relu_in else x[f0:f0 + 64], scale_factor=2)
+        xin = F.pad(xin, (1, 1, 1, 1)).double()
+        gyc_ = gy[f0:f0 + 64].double().permute(1, 0, 2, 3).reshape(Cout, -1)
+        for ky in range(3):
+            for kx in range(3):
+                win = xin[:, :, ky:ky + S, kx:kx + S].permute(1, 0, 2, 3).reshape(Cin, -1)
+                dw_ref[:, :, ky, kx] += gyc_ @ win.t()
+    xc, gyc = K.to_cl(x, torch.bfloat16), K.to_cl(gy, torch.bfloat16)
+    dw, db = torch.zeros(Cout, Cin, 3, 3, device=dev), torch.zeros(Cout, device=dev)
+    K.conv_wgrad(xc, gyc, dw, (3, 3), Cout, Cin, up2=True, relu_in=relu_in, dbias=db)
+    assert rel(dw, dw_ref) < 1e-5
+    assert rel(db, db_ref) < 2e-5      # (3.1 M - 12.5 M fp32 additions per channel)
+    dw2 = torch.full_like(dw, 7.0)
+    K.conv_wgrad(xc, gyc, dw2, (3, 3), Cout, Cin, up2=True, relu_in=relu_in, overwrite=True)
+    assert torch.equal(dw2, dw)                          # fixed-order reduction: the same bits, written instead of added to zeros
+    K.conv_wgrad(xc, gyc, dw2, (3, 3), Cout, Cin, up2=True, relu_in=relu_in)
+    assert rel(dw2, 2 * dw_ref) < 1e-5
