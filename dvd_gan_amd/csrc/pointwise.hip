@@ -274,7 +274,10 @@ __global__ __launch_bounds__(256) void cbn_bwd_apply_kernel(const T* __restrict_
     }
     const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
     const size_t base = (size_t)frame * P * ld + gi * 8;
-    constexpr int U = 2;
+#ifndef DVD_CBN_U
+#define DVD_CBN_U 2
+#endif
+    constexpr int U = DVD_CBN_U;
     for (int p = p0 + j; p < p1; p += nj * U) {
         float gv[U][8], xv[U][8];
 #pragma unroll
@@ -607,7 +610,10 @@ extern "C" int dvd_cbn_backward_apply(int dtype, const void* g, const void* a, c
     if (frames <= 0 || P <= 0 || rows_total < frames * P) return DVD_E_ARG;
     if ((ld & 7) || C > ld || ld / 8 > 256) return DVD_E_SHAPE;
     const float inv_n = (float)(1.0 / (double)rows_total);
-    const int nj = 256 / (ld / 8), chunk2 = nj * 16;
+#ifndef DVD_CBN_CH                     // rows per workgroup = nj * 64 (16: 32 x 32 x 128 frames 930 -> 850 us, 16 x 16 x 256 543 -> 495 incl. the reduce pass; U = 4: nothing)
+#define DVD_CBN_CH 64
+#endif
+    const int nj = 256 / (ld / 8), chunk2 = nj * DVD_CBN_CH;
     dim3 grid2((unsigned)frames, cdiv(P, chunk2));
     BY_DTYPE(dtype, cbn_bwd_apply_kernel<T><<<grid2, 256, 0, S_>>>((const T*)g, (const T*)x, (T*)dx, P, C,
                                                                    ld, mean, rstd, gb, samp, s12, inv_n, relu, chunk2));
