@@ -1390,7 +1390,11 @@ static int wgrad_plan1(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int
         // one round 451.3 / 451.8 ms, two 452.1 / 452.3, three 454.5 / 454.2 (half the slice workspace per halving) -- two rounds
         // beyond 6 M rows (configs[3], 4x the rows per launch: one round 1802 ms, two 1739)
         const long long tgt4 = M > (6ll << 20) ? 512 : 256;
-        msplit = ((mode == 2 ? tgt4 : mode == 1 ? tgt_row : tgt) + base - 1) / base;
+#ifndef DVD_WG_TGT1                    // 64-channel output tile: 2-wave workgroups, three per CU -> one round of 768 (tools/conv_microbench.py wgrad
+#define DVD_WG_TGT1 768                // 30,32 incl. reduce + bias kernels, interleaved: 512 1736 / 314 us, 768 1537 / 264, 1536 1597 / 322, 3072 1648 / 326)
+#endif
+        const long long tgt1 = (mode == 1 && ta == 1) ? (long long)DVD_WG_TGT1 : tgt_row;
+        msplit = ((mode == 2 ? tgt4 : mode == 1 ? tgt1 : tgt) + base - 1) / base;
         long long cap = M / minrows > 0 ? M / minrows : 1;
         if (ntaps == 1 && cap * base < 256) {
             // short 1 x 1 layers (shortcut and attention projections on <= 16-pixel maps): 16 workgroups of 4096 rows each took
@@ -1401,7 +1405,7 @@ static int wgrad_plan1(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int
         if (msplit > cap) msplit = cap;
         // whole rounds: the workgroups run `conc` at a time (register / LDS limited); a grid a few workgroups over a
         // multiple of that pays a full extra round (20 x 103 = 2060 workgroups = 8.05 rounds of 256 -> 9 rounds)
-        const long long conc = 256ll * ((mode >= 1 && (ta == 4 || tb == 2)) ? 1 : 2);
+        const long long conc = 256ll * ((mode >= 1 && (ta == 4 || tb == 2)) ? 1 : (mode == 1 && ta == 1 && DVD_WG_TGT1 > 512) ? 3 : 2);
         if (base * msplit > conc) {
             const long long rounds = (base * msplit + conc / 2) / conc;           // nearest
             long long ms2 = rounds * conc / base;
