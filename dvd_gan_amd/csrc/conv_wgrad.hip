@@ -758,9 +758,11 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
 // workspace; wgrad_fold_reduce_kernel forms dw from them.  p.H / p.W / p.M are the INPUT grid's, p.Cout = p.Cy = 4 * cout_f.
 template <int KW, int AW, int BW, int WCO, int WCI, bool RELU, int DEPTH = 2, bool FOLD = false>
 __global__ __launch_bounds__(256) void conv_wgrad_row4_kernel(WgK p) {
-    // bias column sums: eight registers, except on the pinned tile (no register left): an LDS table updated with ds_add_f32 -- SLOW
-    // (a launch with a bias gradient ran 2x longer), so the planner never sends a bias gradient to that tile; the path only keeps it correct
-    constexpr bool BLDS = KW == 3 && AW * BW * KW > 16;        // (5 taps: 20 tiles, four of them in VGPRs -- registers to spare)
+    // bias column sums: eight registers.  The pinned tile with two staging sets has none left (an LDS table updated with ds_add_f32 ran
+    // such launches 2x longer: that form only stays correct, the planner does not use it): launches with a bias gradient take the pinned
+    // tile with ONE staging set (DEPTH 1, 222 + 256 registers) -- 786 k x 256 -> 256 incl. reduce / bias kernels 1050 -> 950 us against
+    // the 128 x 128 tile they took before (depth 2 is worth 6.5 % on that tile, the larger tile 18 %)
+    constexpr bool BLDS = KW == 3 && AW * BW * KW > 16 && DEPTH >= 2;        // (5 taps: 20 tiles, four of them in VGPRs -- registers to spare; DEPTH 1: one staging set less)
     static_assert(WCO * WCI == 4, "four waves, one per SIMD");
     constexpr int NTt = 256, BMc = WCO * AW * 32, NHB = WCI * BW, BNc = NHB * 32;
     constexpr int RSA = BMc * 2 + 64;
@@ -1350,13 +1352,16 @@ static int wgrad_plan1(const dvd_wgrad_desc* d, WgK& p, dim3& grid, int& ta, int
 #define DVD_ROW4_DEPTH 2
 #endif
         // round 6: one wave per SIMD with the whole register file (conv_wgrad_row4_kernel), mode 2.
-        //   3 taps: 256 x 128 channels (pinned, 24 tiles; not with a bias gradient) or 128 x 128
+        //   3 taps: 256 x 128 channels (pinned, 24 tiles; with a bias gradient: one staging set) or 128 x 128
         //   5 taps: 256 x 64 or 128 x 128 (20 tiles)
         // Needs a round of workgroups with >= 4096 rows each (256 x 256 channels on 48 k rows ran 172 us against 101 on the 8-wave tile);
         // a caller-forced split (msplit > 0: tests) takes the tile whatever the size.
         if (DVD_WG_ROW4 && !d->up2 && ta >= 2 && (d->kw == 3 ? ci128 : (DVD_WG_ROW4 >= 3 && (ta == 4 || ci128)))) {
             int t4 = ta, b4 = 2;
-            if (d->kw == 3) { if (DVD_WG_ROW4 == 1 || d->dbias || fold) t4 = 2; }
+#ifndef DVD_WG_PIN_BIAS                // 1 = launches with a bias gradient take the pinned tile too, with ONE staging set (DEPTH 1) so that the column sums have registers
+#define DVD_WG_PIN_BIAS 1
+#endif
+            if (d->kw == 3) { if (DVD_WG_ROW4 == 1 || (d->dbias && !DVD_WG_PIN_BIAS) || fold) t4 = 2; }
             else if (ta == 4) b4 = 1;
             const long long wgs = (long long)((d->Cout + t4 * 64 - 1) / (t4 * 64)) * ((d->Cin_real + b4 * 64 - 1) / (b4 * 64)) * d->kt * d->kh * (M / 4096);
             if (wgs >= 224 || d->msplit > 0) { mode = 2; tb = b4; ta = t4; }
@@ -1520,7 +1525,7 @@ extern "C" int dvd_conv_wgrad(const dvd_wgrad_desc* d, void* stream) {
                 }
                 return launch_status();
             }
-            if (d->kw == 3) { if (ta == 4) LAUNCH_ROW4(3, 4, 2, 2, 2, 2); else LAUNCH_ROW4(3, 4, 1, 1, 4, DVD_ROW4_DEPTH); }
+            if (d->kw == 3) { if (ta == 4 && p.dbias) LAUNCH_ROW4(3, 4, 2, 2, 2, 1); else if (ta == 4) LAUNCH_ROW4(3, 4, 2, 2, 2, 2); else LAUNCH_ROW4(3, 4, 1, 1, 4, DVD_ROW4_DEPTH); }
             else            { if (ta == 4) LAUNCH_ROW4(5, 4, 1, 2, 2, 2); else LAUNCH_ROW4(5, 4, 1, 1, 4, 2); }
 #undef LAUNCH_ROW4
         } else
